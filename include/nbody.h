@@ -1,0 +1,257 @@
+/*
+ * nbody.h -- C ABI of the MI355X-native N-body engine (libnbody_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of arpan-dhatt/wgpu-n-body: the
+ * per-step force accumulation + kick-drift-kick integrator that the reference
+ * runs as WGSL compute shaders behind `trait Simulator`, driven by
+ * `OfflineHeadless<T>`.  Every entry point below cites the reference interface
+ * it replaces (paths are relative to the reference crate root).
+ *
+ * Conventions
+ *   - plain C, POD structs, plain pointers and sizes; no C++/torch types.
+ *   - every function returning `int` returns NB_OK (0) on success or an
+ *     nb_status code; a human-readable message for the calling thread's last
+ *     failure is available from nb_last_error().  Nothing unwinds across the
+ *     ABI (the reference's constructors return anyhow::Result,
+ *     src/sims/mod.rs:80; its step() panics, src/sims/tree.rs:278-280 -- here
+ *     both become status codes).
+ *   - single caller thread per handle, not re-entrant (same as the reference:
+ *     `Simulator` has no Send/Sync bound, src/sims/mod.rs:73-90).
+ *   - there is NO CPU fallback: if no HIP device is usable, create() fails with
+ *     NB_ERR_NO_DEVICE.
+ */
+#ifndef NBODY_H_
+#define NBODY_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Data model (byte-exact mirrors of the reference's #[repr(C)] PODs)         */
+/* ------------------------------------------------------------------------- */
+
+/* `struct Particle`, src/sims/mod.rs:9-16 (WGSL mirror naive.wgsl:1-6,
+ * array stride 40, naive.wgsl:15-17).  40 bytes, 10 x f32. */
+typedef struct nb_particle {
+    float position[3];
+    float velocity[3];
+    float acceleration[3]; /* stored quantity is sum(f)*dt, naive.wgsl:41 */
+    float mass;
+} nb_particle;
+
+/* `struct SimParams`, src/sims/mod.rs:51-58.  16 bytes. */
+typedef struct nb_sim_params {
+    uint32_t particle_num;
+    float g;
+    float e;
+    float dt;
+} nb_sim_params;
+
+/* `SimParams::default()`, src/sims/mod.rs:62-71 */
+#define NB_DEFAULT_PARTICLE_NUM 10000u
+#define NB_DEFAULT_G 0.000001f
+#define NB_DEFAULT_E 0.0001f
+#define NB_DEFAULT_DT 0.016f
+/* default theta when a TreeSim gets no TreeSimParams, src/sims/tree.rs:42-51 */
+#define NB_DEFAULT_THETA 0.75f
+/* `PARTICLES_PER_GROUP`, src/sims/mod.rs:7 (the reference's workgroup size;
+ * kept for API parity -- the HIP kernels choose their own tiling). */
+#define NB_PARTICLES_PER_GROUP 64u
+
+/* `enum AddParams`, src/sims/mod.rs:18-23 */
+typedef enum nb_add_kind {
+    NB_NAIVE_SIM_PARAMS = 0, /* AddParams::NaiveSimParams            */
+    NB_TREE_SIM_PARAMS = 1   /* AddParams::TreeSimParams { theta }   */
+} nb_add_kind;
+
+typedef struct nb_add_params {
+    int32_t kind; /* nb_add_kind */
+    float theta;  /* only read when kind == NB_TREE_SIM_PARAMS; <= 0 -> default */
+} nb_add_params;
+
+/* `struct Octant`, src/sims/tree.rs:605-622 (WGSL mirror tree.wgsl:1-6,
+ * stride 52, tree.wgsl:31-33).  52 bytes.  Returned by nb_sim_read_tree. */
+typedef struct nb_octant {
+    float cog[3];
+    float mass;
+    uint32_t bodies;
+    uint32_t children[8]; /* 0 = no child; for a leaf (bodies==1) children[0] is
+                             the body's index in the step's source order */
+} nb_octant;
+
+/* The init callback: `init_fn: fn(&SimParams) -> Vec<Particle>`,
+ * src/sims/mod.rs:79 / src/runners/offline_headless.rs:20.  The callee fills
+ * out[0 .. params->particle_num).  `user` is an opaque cookie (the Rust fn
+ * pointer has no environment; a C callback needs one). */
+typedef void (*nb_init_fn)(const nb_sim_params *params, nb_particle *out, void *user);
+
+typedef enum nb_status {
+    NB_OK = 0,
+    NB_ERR_INVALID = 1,    /* bad argument */
+    NB_ERR_NO_DEVICE = 2,  /* no usable HIP device */
+    NB_ERR_HIP = 3,        /* a HIP runtime call failed */
+    NB_ERR_ALLOC = 4,      /* host or device allocation failed */
+    NB_ERR_UNSUPPORTED = 5 /* valid request this build does not implement */
+} nb_status;
+
+/* Message describing the calling thread's most recent failing call ("" if none). */
+const char *nb_last_error(void);
+/* "nbody_hip <semver> gfx950" */
+const char *nb_version(void);
+/* Number of visible HIP devices (0 when there is none or the runtime fails). */
+int nb_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Inits -- seeded equivalents of src/inits.rs                                */
+/* ------------------------------------------------------------------------- */
+/* The reference draws from rand::thread_rng() (src/inits.rs:7,30,58), which
+ * is OS-seeded and not reproducible; these reproduce the *distributions* with
+ * a counter-based generator specified bit-exactly in DESIGN.md ("RNG").
+ * All three have the nb_init_fn signature.  `user` is NULL (seed 0) or points
+ * to a uint64_t seed. */
+void nb_init_uniform(const nb_sim_params *params, nb_particle *out, void *user);   /* inits.rs:6-27  */
+void nb_init_disc(const nb_sim_params *params, nb_particle *out, void *user);      /* inits.rs:29-54 */
+void nb_init_spherical(const nb_sim_params *params, nb_particle *out, void *user); /* inits.rs:56-83 */
+
+/* ------------------------------------------------------------------------- */
+/* Simulator -- `trait Simulator`, src/sims/mod.rs:73-90                      */
+/* ------------------------------------------------------------------------- */
+typedef struct nb_sim nb_sim;
+
+/* Where a simulator lives and which bodies it owns.
+ *
+ * Single GPU: { device_id, 0, 1, NULL, {NULL,NULL} }.
+ *
+ * Multi GPU (one process per GPU): rank r of `world` owns the contiguous body
+ * range [r*per, min(N,(r+1)*per)) with per = nb_shard_bodies_per_rank(N, world).
+ * Each step writes only that slice of the new position/mass buffer; the caller
+ * all-gathers the slices (RCCL) before the next nb_sim_encode.  There is no
+ * reference counterpart (single adapter, src/runners/offline_headless.rs:22-31).
+ *
+ * `stream`: a hipStream_t the kernels are enqueued on, or NULL to let the
+ * simulator create its own.  `posm[0..1]`: optional caller-owned device
+ * buffers for the two ping-pong position/mass arrays (float4 x
+ * nb_shard_padded_bodies(N, world) each, 16-byte aligned) -- this is how a host
+ * that owns device memory (e.g. torch + torch.distributed) runs the collective
+ * in place; NULL lets the simulator allocate them. */
+typedef struct nb_placement {
+    int32_t device_id;
+    int32_t rank;
+    int32_t world;
+    void *stream;
+    void *posm[2];
+} nb_placement;
+
+/* Bodies per rank (a multiple of the kernels' i-tile) and the padded length of
+ * the position/mass buffers (= world * per_rank >= N). */
+size_t nb_shard_bodies_per_rank(size_t particle_num, int world);
+size_t nb_shard_padded_bodies(size_t particle_num, int world);
+
+/* `Simulator::new(device, sim_params, add_params, mappable_primary_buffers,
+ * init_fn)`, src/sims/mod.rs:74-82; NaiveSim::new src/sims/naive.rs:20-145,
+ * TreeSim::new src/sims/tree.rs:29-260.  `device` becomes nb_placement;
+ * `mappable_primary_buffers` has no HIP meaning and is dropped.  add_params
+ * selects the implementation: NB_NAIVE_SIM_PARAMS -> all-pairs (NaiveSim),
+ * NB_TREE_SIM_PARAMS -> Barnes-Hut (TreeSim).  placement may be NULL
+ * (device 0, single GPU).  init runs on the host exactly once, for all
+ * particle_num bodies (every rank must supply identical data). */
+int nb_sim_create(nb_sim **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
+                  const nb_placement *placement, nb_init_fn init, void *user);
+
+/* Same, from an existing particle array instead of a callback
+ * (snapshot/restore; also how tests feed identical bytes to the
+ * oracle and the GPU). */
+int nb_sim_create_from_particles(nb_sim **out, const nb_sim_params *sim_params,
+                                 const nb_add_params *add_params, const nb_placement *placement,
+                                 const nb_particle *particles, size_t n);
+
+/* `Simulator::encode(&mut self, device, queue) -> CommandEncoder`
+ * (src/sims/mod.rs:83; NaiveSim::encode src/sims/naive.rs:147-162,
+ * TreeSim::encode src/sims/tree.rs:262-353) fused with the runner's
+ * `queue.submit` (src/runners/offline_headless.rs:40): enqueues ONE step on
+ * the simulator's stream and returns without waiting; flips the ping-pong
+ * (naive.rs:156,160). */
+int nb_sim_encode(nb_sim *sim);
+
+/* `Simulator::cleanup(&mut self)`, src/sims/mod.rs:87-89 (TreeSim resets its
+ * arena, src/sims/tree.rs:363-365).  Host-side housekeeping that may overlap
+ * the enqueued step.  No-op for the all-pairs simulator. */
+int nb_sim_cleanup(nb_sim *sim);
+
+/* `device.poll(wgpu::Maintain::Wait)`, src/runners/offline_headless.rs:43:
+ * block until everything enqueued on the simulator's stream has finished. */
+int nb_sim_wait(nb_sim *sim);
+
+/* `Simulator::sim_params(&self) -> SimParams`, src/sims/mod.rs:85. */
+int nb_sim_sim_params(const nb_sim *sim, nb_sim_params *out);
+
+/* `Simulator::dest_particle_slice(&self)`, src/sims/mod.rs:84 -- with one
+ * documented deviation: the reference's slice is the buffer the last step READ
+ * (src/sims/naive.rs:164-166 after step_num += 1); this returns
+ * the POST-step state.  Waits for the stream, converts the device SoA state
+ * to the 40-byte AoS layout and copies dst[0 .. n).  On a sharded simulator
+ * only position/mass are globally valid (after the caller's all-gather);
+ * velocity/acceleration are filled for the rank's own range and zero
+ * elsewhere. */
+int nb_sim_read_particles(nb_sim *sim, nb_particle *dst, size_t n);
+
+/* Overwrite the simulator state (checkpoint restore). */
+int nb_sim_write_particles(nb_sim *sim, const nb_particle *src, size_t n);
+
+/* TreeSim only: copy out the octree the LAST step built (node count via
+ * *n_nodes; up to cap entries written), in the reference's node numbering
+ * (allocation order of src/sims/tree.rs:461,517-519).  NB_ERR_UNSUPPORTED on
+ * an all-pairs simulator. */
+int nb_sim_read_tree(nb_sim *sim, nb_octant *dst, size_t cap, size_t *n_nodes, float *root_width);
+
+/* Sharded use: the device pointer of the position/mass buffer the LAST encode
+ * wrote (float4 per body: x, y, z, mass), this rank's byte offset and byte
+ * length inside it, and the total length.  The caller all-gathers
+ * [offset, offset+slice) of every rank in place. */
+int nb_sim_exchange_region(nb_sim *sim, void **dev_ptr, size_t *offset_bytes, size_t *slice_bytes,
+                           size_t *total_bytes);
+
+/* Step counter (`step_num`, src/sims/naive.rs:160). */
+int nb_sim_step_num(const nb_sim *sim, uint64_t *out);
+
+/* Time the next `n` encodes with HIP events on the simulator's own stream:
+ * enqueue n steps back to back, wait, and report the total in *ms_total and
+ * the mean duration of the dominant force kernel in *ms_kernel (events
+ * bracket that launch alone).  Used by bench.py for `roofline.achieved`. */
+int nb_sim_encode_n_timed(nb_sim *sim, int n, float *ms_total, float *ms_kernel);
+
+int nb_sim_destroy(nb_sim *sim);
+
+/* ------------------------------------------------------------------------- */
+/* Runner -- `OfflineHeadless<T>`, src/runners/offline_headless.rs:4-45       */
+/* ------------------------------------------------------------------------- */
+typedef struct nb_runner nb_runner;
+
+/* `OfflineHeadless::<T>::new(sim_params, add_params, init_fn)`,
+ * offline_headless.rs:17-35: acquires the device (here: device_id, or -1 for
+ * "highest-performance adapter" = device 0) and constructs the simulator T
+ * selected by add_params.kind. */
+int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
+                     const nb_add_params *add_params, nb_init_fn init, void *user, int device_id);
+
+/* `OfflineHeadless::step(&mut self)`, offline_headless.rs:38-44:
+ * encode -> submit -> cleanup -> blocking wait. */
+int nb_runner_step(nb_runner *runner);
+
+/* n steps enqueued back to back, one wait at the end (benchmark use). */
+int nb_runner_step_n(nb_runner *runner, int n);
+
+int nb_runner_read_particles(nb_runner *runner, nb_particle *dst, size_t n);
+int nb_runner_sim_params(const nb_runner *runner, nb_sim_params *out);
+/* Borrow the runner's simulator (owned by the runner). */
+nb_sim *nb_runner_sim(nb_runner *runner);
+int nb_runner_destroy(nb_runner *runner);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_H_ */
