@@ -224,6 +224,14 @@ int nb_sim_step_num(const nb_sim *sim, uint64_t *out);
  * bracket that launch alone).  Used by bench.py for `roofline.achieved`. */
 int nb_sim_encode_n_timed(nb_sim *sim, int n, float *ms_total, float *ms_kernel);
 
+/* Tuning knobs with no reference counterpart.  key "naive_variant": index into the
+ * all-pairs kernel variant table (tiling / packing choices of nb_naive.hip; every variant
+ * computes the same step).  Also settable through the NB_NAIVE_VARIANT environment
+ * variable at create time. */
+int nb_sim_set_tuning(nb_sim *sim, const char *key, int value);
+int nb_naive_variant_count(void);
+const char *nb_naive_variant_name(int variant);
+
 int nb_sim_destroy(nb_sim *sim);
 
 /* ------------------------------------------------------------------------- */

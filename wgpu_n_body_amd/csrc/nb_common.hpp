@@ -1,0 +1,62 @@
+// nb_common.hpp -- internal declarations shared by the host side (nb_abi.cpp) and the
+// HIP translation units.  Not part of the C ABI (include/nbody.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "nbody.h"
+
+namespace nb {
+
+// ---- error plumbing: every failure records a message for nb_last_error() ----
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define NB_HIP_TRY(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t nb_e_ = (expr);                                                             \
+        if (nb_e_ != hipSuccess) {                                                             \
+            ::nb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(nb_e_), __FILE__, \
+                            __LINE__);                                                         \
+            return NB_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+// ---- all-pairs tiling constants ---------------------------------------------
+// One workgroup owns an i-tile of NB_ITILE bodies; its waves split the j range.
+constexpr uint32_t kWave = 64;
+constexpr uint32_t kIB = 2;                    // bodies per lane (i-blocking)
+constexpr uint32_t kITile = kWave * kIB;       // bodies per workgroup = 128
+constexpr uint32_t kJTile = 64;                // bodies per wave-load of the j stream
+constexpr uint32_t kPadTo = 256;               // posm buffers are padded to a multiple of this
+
+// ---- launchers implemented in nb_naive.hip ----------------------------------
+struct NaiveLaunch {
+    const float4 *posm_src;  // [n_pad] x,y,z,m  (previous step, all bodies)
+    float4 *posm_dst;        // [n_pad] this step's positions; only [lo,hi) written
+    float4 *vel;             // [hi-lo padded] this rank's velocities (in place)
+    float4 *acc;             // [hi-lo padded] this rank's stored accelerations (in place)
+    uint32_t n;              // real bodies
+    uint32_t n_pad;          // allocated bodies (multiple of kPadTo, zero-filled tail)
+    uint32_t lo, hi;         // this rank's body range
+    float g, e, dt;
+    int variant;             // kernel variant (see nb_naive.hip); <0 = default
+};
+hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream);
+int naive_variant_count();
+const char *naive_variant_name(int v);
+
+// AoS (nb_particle, 40 B) <-> device SoA conversion, body range [lo,hi) of `aos` (indexed
+// globally) <-> posm[lo..hi) (global index) and vel/acc (local index i-lo).
+hipError_t launch_aos_to_soa(const nb_particle *aos, float4 *posm, float4 *vel, float4 *acc,
+                             uint32_t n, uint32_t lo, uint32_t hi, hipStream_t stream);
+hipError_t launch_soa_to_aos(const float4 *posm, const float4 *vel, const float4 *acc,
+                             nb_particle *aos, uint32_t n, uint32_t lo, uint32_t hi,
+                             hipStream_t stream);
+
+}  // namespace nb

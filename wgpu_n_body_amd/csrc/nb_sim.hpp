@@ -1,0 +1,76 @@
+// nb_sim.hpp -- internal simulator classes behind the opaque nb_sim handle.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "nb_common.hpp"
+
+namespace nb {
+
+// What `trait Simulator` (src/sims/mod.rs:73-90) requires of an implementor, in HIP terms.
+class SimBase {
+   public:
+    virtual ~SimBase();
+
+    int setup_common(const nb_sim_params &p, const nb_add_params &ap, const nb_placement *pl);
+    int bind_device() const;
+    int wait();
+
+    virtual int init(const nb_particle *host, size_t count) = 0;          // Simulator::new
+    virtual int encode() = 0;                                             // Simulator::encode
+    virtual int cleanup() { return NB_OK; }                               // Simulator::cleanup
+    virtual int read_particles(nb_particle *dst, size_t count) = 0;       // dest_particle_slice
+    virtual int write_particles(const nb_particle *src, size_t count) = 0;
+    virtual int encode_n_timed(int count, float *ms_total, float *ms_kernel) = 0;
+    virtual int exchange_region(void **, size_t *, size_t *, size_t *) {
+        set_error("this simulator has no exchange region");
+        return NB_ERR_UNSUPPORTED;
+    }
+    virtual int read_tree(nb_octant *, size_t, size_t *, float *) {
+        set_error("read_tree: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
+    virtual int set_tuning(const char *key, int) {
+        set_error("unknown tuning key '%s'", key);
+        return NB_ERR_INVALID;
+    }
+
+    nb_sim_params params{};
+    nb_add_params add{};
+    nb_placement place{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t step_num = 0;
+    uint32_t n = 0, n_pad = 0, per_rank = 0, lo = 0, hi = 0;
+};
+
+class NaiveSim final : public SimBase {
+   public:
+    ~NaiveSim() override;
+    int init(const nb_particle *host, size_t count) override;
+    int encode() override;
+    int read_particles(nb_particle *dst, size_t count) override;
+    int write_particles(const nb_particle *src, size_t count) override;
+    int encode_n_timed(int count, float *ms_total, float *ms_kernel) override;
+    int exchange_region(void **dev_ptr, size_t *off, size_t *len, size_t *total) override;
+    int set_tuning(const char *key, int value) override;
+
+   private:
+    float4 *posm[2] = {nullptr, nullptr};  // ping-pong position/mass (naive.rs:99-132)
+    bool own_posm = true;
+    float4 *vel = nullptr, *acc = nullptr;  // this rank's bodies only
+    nb_particle *d_aos = nullptr;           // AoS staging for the 40-byte boundary layout
+    int cur = 0;                            // posm[cur] holds the current state
+    int variant = -1;
+    std::vector<hipEvent_t> events;
+};
+
+// Implemented in nb_tree.hip; returns nullptr when the tree path is not built.
+SimBase *make_tree_sim();
+
+}  // namespace nb
+
+struct nb_sim {
+    std::unique_ptr<nb::SimBase> impl;
+};
