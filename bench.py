@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark: pair interactions/s of the all-pairs step at 65,536
+bodies (BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one NaiveSim step (nb_sim_encode: kick-drift, all-pairs force accumulation,
+second kick) over all 65,536 bodies; with N > 1 the bodies are partitioned by index range,
+one rank per GPU, and each step ends with the in-place RCCL all-gather of the new
+position/mass slices (strong scaling: the problem stays 65,536 bodies).  Inputs are
+synthetic (the seeded uniform_init the reference's own criterion bench uses,
+benches/benchmark.rs:24) and are resident in HBM before the timed region starts.
+
+Rank 0 prints ONE JSON line.  `value` = N*(N-1)*K / wall seconds over all GPUs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20            # SURVEY 8(d) / BASELINE.md: the fixed N-body convention
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 vector == FP32 matrix (MFMA f32) peak
+G, E, DT = 0.000001, 0.0001, 0.016
+
+
+def cpu_baseline(nb, init_floats, n, target_seconds=12.0):
+    """The CPU oracle (fp32 restatement of naive.wgsl, OpenMP over bodies) on a bounded
+    sample of the SAME workload: the first `m` bodies' step against all n bodies."""
+    from oracle import oracle as O
+    threads = O.max_threads()
+    probe = min(n, 64 * max(threads, 1))
+    t0 = time.perf_counter()
+    O.naive_step_f32(init_floats, G, E, DT, 0, probe)
+    dt_probe = max(time.perf_counter() - t0, 1e-6)
+    m = int(min(n, max(probe, probe * target_seconds / dt_probe)))
+    m = max(16, (m // 16) * 16)
+    t0 = time.perf_counter()
+    O.naive_step_f32(init_floats, G, E, DT, 0, m)
+    secs = time.perf_counter() - t0
+    pairs = m * (n - 1)
+    return {"value": pairs / secs, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "isa": O.isa(),
+            "sample": f"one all-pairs step of the first {m} of {n} bodies against all {n} "
+                      f"({pairs:.3e} pairs, {secs:.1f} s); full step would take "
+                      f"{secs * n / m * 1e3:.0f} ms"}
+
+
+def hbm_traffic_from_profile(n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_summary.json, collected as MI355X_MICROARCH.md prescribes); null if the
+    summary does not cover this N."""
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
+            d = json.load(open(path))
+            if int(d.get("n", -1)) == n and d.get("hbm_bytes_per_launch") is not None:
+                return float(d["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bodies", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None, help="all-pairs kernel variant override")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: libnbody_hip.so then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+
+    import wgpu_n_body_amd as nb
+    from wgpu_n_body_amd.sharded import ShardedNaiveSim
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available() or nb.device_count() == 0:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.bodies
+    sp = nb.SimParams(particle_num=n, g=G, e=E, dt=DT)
+    init = nb.inits.uniform_init(sp, seed=2)          # identical bytes on every rank
+    K, W = args.steps, args.warmup
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ms_kernel = None
+    if world == 1:
+        sim = nb.NaiveSim.from_particles(sp, None, init, nb.Placement(device_id=local_rank))
+        if args.variant is not None:
+            sim.set_tuning("naive_variant", args.variant)
+        for _ in range(W):
+            sim.encode()
+        sim.wait()
+        sync_all()
+        t0 = time.perf_counter()
+        # K steps back to back on the simulator's stream, HIP events around each launch
+        _ms_total, ms_kernel = sim.encode_n_timed(K)
+        sync_all()
+        wall = time.perf_counter() - t0
+    else:
+        sim = ShardedNaiveSim(sp, init, rank, world, local_rank, variant=args.variant)
+        for _ in range(W):
+            sim.encode()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            sim.encode()
+        sync_all()
+        wall = time.perf_counter() - t0
+        # kernel-only duration, measured separately so the timed region stays undisturbed
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(min(K, 10))]
+        for pair in ev:
+            sim.encode(events=pair)
+        sync_all()
+        ms_kernel = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    # sanity: the state is finite after the run (a diverged run is not a benchmark)
+    state = nb.as_floats(sim.read_particles() if world > 1 else sim.dest_particle_slice())
+    assert np.isfinite(state).all(), "non-finite state after the timed steps"
+
+    if rank == 0:
+        pairs_per_step = n * (n - 1)
+        value = pairs_per_step * K / wall
+        per_rank = nb.shard_bodies_per_rank(n, world)
+        local_pairs = min(per_rank, n) * (n - 1)              # pairs one launch evaluates
+        achieved = FLOP_PER_PAIR * local_pairs / (ms_kernel * 1e-3) / 1e12
+        out = {
+            "metric": "body-pair interactions/sec, 64k-body all-pairs",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall / K * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}-body naive all-pairs step (BASELINE configs[1]), "
+                                   f"uniform_init seed 2, g=1e-6 e=1e-4 dt=0.016",
+                       "bodies": n, "pairs_per_step": pairs_per_step,
+                       "parallelism": f"body-range shard x{world}" + (
+                           " + RCCL all-gather of float4 positions per step" if world > 1 else ""),
+                       "kernel_variant": (nb.naive_variants()[args.variant]
+                                          if args.variant is not None else "auto")},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": hbm_traffic_from_profile(n) if world == 1 else None,
+                         "kernel": "nb::naive_step_kernel", "kernel_ms": ms_kernel,
+                         "flop_per_pair": FLOP_PER_PAIR,
+                         "note": "compute-bound on FP32 VALU issue; 157.3 TFLOP/s is both the "
+                                 "vector and the f32-MFMA dense peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nb, nb.as_floats(init), n)
+        print(json.dumps(out), flush=True)
+
+    sim.destroy()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

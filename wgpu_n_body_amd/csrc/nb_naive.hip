@@ -306,7 +306,15 @@ const Variant kVariants[] = {
     NB_V(4, 16, kLds, true, 2),   // 14
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 0;
+
+// Default choice by the number of bodies this launch owns: keep >= ~256 workgroups (one per
+// CU) in flight, then prefer more bodies per lane (fewer LDS reads per pair) and packed fp32.
+// Measured on MI355X at N = 65536 (profiles/r01_variant_sweep.txt): 14 > 7 ~ 3 > 12 > 1.
+int auto_variant(uint32_t n_local) {
+    if (n_local >= 49152u) return 14;  // ib4_w16 packed: 256 WGs x 16 waves at 64k
+    if (n_local >= 12288u) return 12;  // ib2_w16 packed
+    return 10;                         // ib1_w16
+}
 
 }  // namespace
 
@@ -317,7 +325,7 @@ const char *naive_variant_name(int v) {
 
 hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream) {
     if (a.hi <= a.lo) return hipSuccess;  // a rank that owns no bodies
-    const int vi = (a.variant >= 0 && a.variant < kNumVariants) ? a.variant : kDefaultVariant;
+    const int vi = (a.variant >= 0 && a.variant < kNumVariants) ? a.variant : auto_variant(a.hi - a.lo);
     const Variant &v = kVariants[vi];
     const uint32_t itile = 64u * (uint32_t)v.ib;
     const uint32_t blocks = (a.hi - a.lo + itile - 1u) / itile;
