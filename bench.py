@@ -2,7 +2,7 @@
 """bench.py -- the headline benchmark: pair interactions/s of the all-pairs step at 65,536
 bodies (BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -34,24 +34,30 @@ G, E, DT = 0.000001, 0.0001, 0.016
 
 def cpu_baseline(nb, init_floats, n, target_seconds=12.0):
     """The CPU oracle (fp32 restatement of naive.wgsl, OpenMP over bodies) on a bounded
-    sample of the SAME workload: the first `m` bodies' step against all n bodies."""
+    sample of the SAME workload: the step of the first `m` bodies against all n bodies
+    (m sized for ~target_seconds of CPU work; whole steps are repeated if one is shorter).
+    Threads: the box's CPU share for one GPU (16) unless NB_CPU_THREADS says otherwise."""
     from oracle import oracle as O
-    threads = O.max_threads()
-    probe = min(n, 64 * max(threads, 1))
+    threads = int(os.environ.get("NB_CPU_THREADS", "0")) or min(O.max_threads(), 16)
+    O.set_threads(threads)
+    probe = min(n, 64 * threads)
+    O.naive_step_f32(init_floats, G, E, DT, 0, min(n, 16 * threads))       # page in / spin up
     t0 = time.perf_counter()
     O.naive_step_f32(init_floats, G, E, DT, 0, probe)
     dt_probe = max(time.perf_counter() - t0, 1e-6)
     m = int(min(n, max(probe, probe * target_seconds / dt_probe)))
     m = max(16, (m // 16) * 16)
+    reps = 1 if m < n else int(min(20, max(1, round(target_seconds / (dt_probe * n / probe)))))
     t0 = time.perf_counter()
-    O.naive_step_f32(init_floats, G, E, DT, 0, m)
+    for _ in range(reps):
+        O.naive_step_f32(init_floats, G, E, DT, 0, m)
     secs = time.perf_counter() - t0
-    pairs = m * (n - 1)
+    pairs = reps * m * (n - 1)
     return {"value": pairs / secs, "unit": "pairs/s", "cores": threads, "kind": "port",
             "isa": O.isa(),
-            "sample": f"one all-pairs step of the first {m} of {n} bodies against all {n} "
-                      f"({pairs:.3e} pairs, {secs:.1f} s); full step would take "
-                      f"{secs * n / m * 1e3:.0f} ms"}
+            "sample": f"{reps} x the all-pairs step of the first {m} of {n} bodies against all "
+                      f"{n} ({pairs:.3e} pairs in {secs:.1f} s on {threads} threads); a full "
+                      f"step would take {secs / reps * n / m * 1e3:.0f} ms"}
 
 
 def hbm_traffic_from_profile(n):
@@ -72,8 +78,10 @@ def hbm_traffic_from_profile(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the chip needs ~50 steps (~70 ms) of back-to-back launches before its clock
+    # settles (profiles/r01_warmup.txt: 1.51 ms -> 1.26 ms per step), so warm up past that
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--bodies", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=None, help="all-pairs kernel variant override")

@@ -28,11 +28,13 @@ POS_TOL_10 = 2e-6
 VEL_TOL_10 = 2e-5
 
 
-def run_gpu(nb, state, steps, g=G, e=E, dt=DT, variant=None, cls=None):
+def run_gpu(nb, state, steps, g=G, e=E, dt=DT, variant=None, cls=None, jsplit=None):
     sp = nb.SimParams(particle_num=len(state), g=g, e=e, dt=dt)
     sim = (cls or nb.NaiveSim).from_particles(sp, None, state)
     if variant is not None:
         sim.set_tuning("naive_variant", variant)
+    if jsplit is not None:
+        sim.set_tuning("naive_jsplit", jsplit)
     for _ in range(steps):
         sim.encode()
         sim.cleanup()
@@ -131,6 +133,21 @@ def test_every_kernel_variant_agrees(gpu, oracle):
     for v, name in enumerate(gpu.naive_variants()):
         out = run_gpu(gpu, s, 3, variant=v)
         check_against_oracles(out, ref32, ref64, 3)
+
+
+@pytest.mark.parametrize("n,variant,jsplit", [(4096, 14, 1), (4096, 14, 2), (4096, 14, 4),
+                                              (5000, 1, 3), (5000, 12, 4), (2000, 9, 2),
+                                              (8192, None, None), (700, 14, 8)])
+def test_j_split_across_workgroups(gpu, oracle, n, variant, jsplit):
+    """Few bodies per launch: the j range is split over JS workgroups per i-tile and a
+    second kernel adds the partial sums in fixed order.  Same step, same tolerances."""
+    s = make_state("uniform", n, 300 + n)
+    out = run_gpu(gpu, s, 2, variant=variant, jsplit=jsplit)
+    ref32 = oracle.naive_run_f32(s, G, E, DT, 2)
+    ref64 = oracle.naive_run_f64(s, G, E, DT, 2)
+    check_against_oracles(out, ref32, ref64, 2)
+    again = run_gpu(gpu, s, 2, variant=variant, jsplit=jsplit)
+    assert np.array_equal(bits(out), bits(again))   # deterministic (fixed summation order)
 
 
 @pytest.mark.parametrize("kind,g,dt", [("uniform", G, DT), ("spherical", G, DT),
@@ -244,8 +261,9 @@ def _hip():
     raise RuntimeError("libamdhip64 not found")
 
 
-@pytest.mark.parametrize("n,world", [(1000, 2), (5000, 3), (4096, 4)])
-def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world):
+@pytest.mark.parametrize("n,world,jsplit", [(1000, 2, 1), (5000, 3, 1), (4096, 4, 1),
+                                            (4096, 2, 4)])
+def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world, jsplit):
     """`world` simulators, each owning a body range, exchanging position slices by
     device-to-device copy (what the RCCL all-gather does across GPUs) == one simulator."""
     nb = gpu
@@ -254,11 +272,11 @@ def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world):
     sp = nb.SimParams(particle_num=n)
     init = nb.inits.uniform_init(sp, seed=9)
     single = nb.NaiveSim.from_particles(sp, None, init)
-    single.set_tuning("naive_variant", 1)
     sims = [nb.NaiveSim.from_particles(sp, None, init, nb.Placement(0, r, world))
             for r in range(world)]
-    for s in sims:
+    for s in [single] + sims:   # same tiling everywhere => bitwise-equal sums
         s.set_tuning("naive_variant", 1)
+        s.set_tuning("naive_jsplit", jsplit)
     for _ in range(3):
         single.encode()
         for s in sims:

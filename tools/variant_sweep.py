@@ -17,6 +17,7 @@ ap.add_argument("--check-n", type=int, default=3000)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--variants", type=str, default="")
 ap.add_argument("--rounds", type=int, default=2)
+ap.add_argument("--jsplit", type=int, default=0)
 args = ap.parse_args()
 
 names = nb.naive_variants()
@@ -52,6 +53,7 @@ for r in range(args.rounds):
     for v in sel:
         sim = nb.NaiveSim.from_particles(sp, None, big)
         sim.set_tuning("naive_variant", v)
+        sim.set_tuning("naive_jsplit", args.jsplit)
         sim.encode_n_timed(3)
         tot, ker = sim.encode_n_timed(args.steps)
         sim.destroy()

@@ -98,6 +98,7 @@ NaiveSim::~NaiveSim() {
     if (vel) (void)hipFree(vel);
     if (acc) (void)hipFree(acc);
     if (d_aos) (void)hipFree(d_aos);
+    if (partial) (void)hipFree(partial);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
 }
 
@@ -133,7 +134,24 @@ int NaiveSim::init(const nb_particle *host, size_t count) {
     NB_HIP_TRY(hipMemsetAsync(vel, 0, local_bytes, stream));
     NB_HIP_TRY(hipMemsetAsync(acc, 0, local_bytes, stream));
     if (const char *v = getenv("NB_NAIVE_VARIANT")) variant = atoi(v);
+    if (const char *v = getenv("NB_NAIVE_JSPLIT")) jsplit = atoi(v);
+    if (int rc = ensure_workspace()) return rc;
     return write_particles(host, count);
+}
+
+// The j-split path needs room for its partial sums; (re)allocated whenever the plan changes.
+int NaiveSim::ensure_workspace() {
+    const NaivePlan p = plan_naive(n, hi - lo, variant, jsplit);
+    if (p.jsplit > 1 && p.jsplit > partial_slices) {
+        if (int rc = bind_device()) return rc;
+        NB_HIP_TRY(hipStreamSynchronize(stream));
+        if (partial) NB_HIP_TRY(hipFree(partial));
+        partial = nullptr;
+        partial_slices = 0;
+        NB_HIP_TRY(hipMalloc(&partial, sizeof(float4) * (size_t)p.jsplit * (size_t)per_rank));
+        partial_slices = p.jsplit;
+    }
+    return NB_OK;
 }
 
 int NaiveSim::write_particles(const nb_particle *host, size_t count) {
@@ -169,6 +187,10 @@ int NaiveSim::encode() {
     a.e = params.e;
     a.dt = params.dt;
     a.variant = variant;
+    a.jsplit = jsplit;
+    a.partial = partial;
+    a.partial_stride = per_rank;
+    a.partial_slices = partial_slices;
     NB_HIP_TRY(launch_naive_step(a, stream));
     cur ^= 1;
     step_num += 1;
@@ -235,7 +257,15 @@ int NaiveSim::set_tuning(const char *key, int value) {
             return NB_ERR_INVALID;
         }
         variant = value;
-        return NB_OK;
+        return ensure_workspace();
+    }
+    if (strcmp(key, "naive_jsplit") == 0) {
+        if (value < 0 || value > 32) {
+            set_error("naive_jsplit %d out of range [0, 32]", value);
+            return NB_ERR_INVALID;
+        }
+        jsplit = value;
+        return ensure_workspace();
     }
     set_error("unknown tuning key '%s'", key);
     return NB_ERR_INVALID;

@@ -46,7 +46,18 @@ struct NaiveLaunch {
     uint32_t lo, hi;         // this rank's body range
     float g, e, dt;
     int variant;             // kernel variant (see nb_naive.hip); <0 = default
+    int jsplit;              // j-splits across workgroups; <=0 = automatic
+    float4 *partial;         // [partial_slices][partial_stride] partial sums (j-split only)
+    uint32_t partial_stride; // bodies per slice (>= hi-lo)
+    uint32_t partial_slices; // slices allocated
 };
+// How a launch will be shaped for (n total bodies, n_local owned bodies).
+struct NaivePlan {
+    int variant;
+    uint32_t blocks;  // i-tiles
+    uint32_t jsplit;  // workgroups per i-tile (1 = single-kernel step)
+};
+NaivePlan plan_naive(uint32_t n, uint32_t n_local, int variant, int jsplit);
 hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream);
 int naive_variant_count();
 const char *naive_variant_name(int v);

@@ -124,12 +124,17 @@ __device__ __forceinline__ float &elem<v2f>(v2f *a, int k) {
     return reinterpret_cast<float *>(a)[k];  // fully unrolled callers: stays in registers
 }
 
-// grid.x = ceil((hi-lo) / (64*IB)); block = 64*W threads.
+// grid.x = ceil((hi-lo) / (64*IB)) i-tiles; grid.y = JS j-splits; block = 64*W threads.
+// JS == 1: the workgroup sees every j and finishes the step itself.  JS > 1 (few bodies per
+// launch: small N, or one rank's share of a multi-GPU run): workgroup (b, s) sums the j tiles
+// t with (t mod JS*W) in [s*W, (s+1)*W) and writes its partial sums to `partial[s][i-lo]`;
+// naive_finish_kernel then adds the JS partials in order s = 0..JS-1 and integrates.  Either
+// way a body's sum is built in one fixed order: results are deterministic.
 template <int IB, int W, int SRC, bool PACKED, int UNROLL>
 __global__ __launch_bounds__(64 * W) void naive_step_kernel(
     const float4 *__restrict__ posm_src, float4 *__restrict__ posm_dst, float4 *__restrict__ vel,
-    float4 *__restrict__ acc, uint32_t n, uint32_t n_pad, uint32_t lo, uint32_t hi, float g,
-    float e, float dt) {
+    float4 *__restrict__ acc, float4 *__restrict__ partial, uint32_t partial_stride, uint32_t n,
+    uint32_t n_pad, uint32_t lo, uint32_t hi, float g, float e, float dt) {
     static_assert(!PACKED || IB % 2 == 0, "packed fp32 needs an even number of bodies per lane");
     using T = typename std::conditional<PACKED, v2f, float>::type;
     constexpr int NV = PACKED ? IB / 2 : IB;
@@ -140,6 +145,8 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t i0 = lo + blockIdx.x * (64u * IB);  // first body of this workgroup's i-tile
+    const uint32_t slot = blockIdx.y * W + wave;        // this wave's share of the j tiles
+    const uint32_t n_slots = gridDim.y * W;
 
     // ---- kick + drift (naive.wgsl:63-64), every wave redundantly for its own lanes -------
     uint32_t ii[IB];
@@ -170,13 +177,13 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
     const uint32_t t_self_lo = i0 / kJTile, t_self_hi = (i0 + 64u * IB - 1u) / kJTile;
     if constexpr (SRC == kLds) {
         float4 *my = s_tile + wave * 2 * kJTile;
-        uint32_t t = wave;
+        uint32_t t = slot;
         float4 nxt = t < n_tiles ? posm_src[t * kJTile + lane] : float4{0, 0, 0, 0};
         uint32_t buf = 0;
-        for (; t < n_tiles; t += W) {
+        for (; t < n_tiles; t += n_slots) {
             my[buf * kJTile + lane] = nxt;  // ds_write_b128; wave-private, no s_barrier needed
             __builtin_amdgcn_wave_barrier();
-            const uint32_t tn = t + W;
+            const uint32_t tn = t + n_slots;
             if (tn < n_tiles) nxt = posm_src[tn * kJTile + lane];  // prefetch the next tile
             const float4 *tile = my + buf * kJTile;
             const bool special = (t >= t_self_lo && t <= t_self_hi) || (t + 1u == n_tiles);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
             buf ^= 1u;
         }
     } else {
-        for (uint32_t t = wave; t < n_tiles; t += W) {
+        for (uint32_t t = slot; t < n_tiles; t += n_slots) {
             const float4 *tile = posm_src + t * kJTile;  // wave-uniform -> s_load_dwordx4+
             const bool special = (t >= t_self_lo && t <= t_self_hi) || (t + 1u == n_tiles);
             if (special)
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
         }
         __syncthreads();
         if (wave != 0) return;
-#pragma unroll
+#pragma unroll 1  // unrolled over 15 waves x 12 sums the loads all hoist and spill
         for (int w = 1; w < W; ++w) {
             const float *src = s_red + (w - 1) * (IB * 3 * 64);
 #pragma unroll
@@ -230,6 +237,15 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
                 sz[k] += src[(k * 3 + 2) * 64 + lane];
             }
         }
+    }
+
+    if (gridDim.y > 1) {  // j-split: hand the partial sums to naive_finish_kernel
+#pragma unroll
+        for (int k = 0; k < IB; ++k)
+            if (ii[k] < hi)
+                partial[(size_t)blockIdx.y * partial_stride + (ii[k] - lo)] =
+                    float4{sx[k], sy[k], sz[k], 0.0f};
+        return;
     }
 
     // ---- second kick + store (naive.wgsl:66-68) -------------------------------------------
@@ -243,6 +259,32 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
                                  0.0f};
         acc[ii[k] - lo] = float4{fx, fy, fz, 0.0f};
     }
+}
+
+// Second half of a j-split step: one thread per body adds the JS partial sums in fixed order
+// and applies the integrator exactly as the single-kernel path does (naive.wgsl:63-68).
+__global__ __launch_bounds__(256) void naive_finish_kernel(
+    const float4 *__restrict__ posm_src, float4 *__restrict__ posm_dst, float4 *__restrict__ vel,
+    float4 *__restrict__ acc, const float4 *__restrict__ partial, uint32_t partial_stride,
+    uint32_t js, uint32_t lo, uint32_t hi, float g, float dt) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const float4 p = posm_src[i], v = vel[i - lo], a = acc[i - lo];
+    const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (uint32_t s = 0; s < js; ++s) {
+        const float4 q = partial[(size_t)s * partial_stride + (i - lo)];
+        if (s == 0) {
+            sx = q.x; sy = q.y; sz = q.z;
+        } else {
+            sx += q.x; sy += q.y; sz += q.z;
+        }
+    }
+    const float gdt = g * dt;
+    const float fx = sx * gdt, fy = sy * gdt, fz = sz * gdt;
+    posm_dst[i] = float4{drift(p.x, vhx, dt), drift(p.y, vhy, dt), drift(p.z, vhz, dt), p.w};
+    vel[i - lo] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.0f};
+    acc[i - lo] = float4{fx, fy, fz, 0.0f};
 }
 
 // ---- AoS <-> SoA at the boundary ------------------------------------------------------------
@@ -279,8 +321,8 @@ __global__ void soa_to_aos_kernel(const float4 *__restrict__ posm, const float4 
 }
 
 // ---- variant table ----------------------------------------------------------------------------
-using KernelFn = void (*)(const float4 *, float4 *, float4 *, float4 *, uint32_t, uint32_t,
-                          uint32_t, uint32_t, float, float, float);
+using KernelFn = void (*)(const float4 *, float4 *, float4 *, float4 *, float4 *, uint32_t,
+                          uint32_t, uint32_t, uint32_t, uint32_t, float, float, float);
 struct Variant {
     const char *name;
     KernelFn fn;
@@ -304,17 +346,21 @@ const Variant kVariants[] = {
     NB_V(2, 16, kLds, true, 8),   // 12
     NB_V(4, 8, kSmem, true, 4),   // 13
     NB_V(4, 16, kLds, true, 2),   // 14
+    NB_V(4, 8, kLds, true, 2),    // 15
+    NB_V(4, 16, kSmem, true, 2),  // 16
+    NB_V(2, 16, kSmem, true, 8),  // 17
+    NB_V(2, 16, kLds, true, 4),   // 18
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-// Default choice by the number of bodies this launch owns: keep >= ~256 workgroups (one per
-// CU) in flight, then prefer more bodies per lane (fewer LDS reads per pair) and packed fp32.
-// Measured on MI355X at N = 65536 (profiles/r01_variant_sweep.txt): 14 > 7 ~ 3 > 12 > 1.
-int auto_variant(uint32_t n_local) {
-    if (n_local >= 49152u) return 14;  // ib4_w16 packed: 256 WGs x 16 waves at 64k
-    if (n_local >= 12288u) return 12;  // ib2_w16 packed
-    return 10;                         // ib1_w16
-}
+// Default choice by the number of bodies this launch owns.  Measured on MI355X at N = 65536
+// (profiles/r01_variant_sweep*.txt): 4 bodies per lane, packed fp32, 16 waves per workgroup
+// (variant 14) is the fastest single-kernel shape at 256 workgroups; with fewer i-tiles than
+// CUs the j range is additionally split over JS workgroups per i-tile so that >= ~256
+// workgroups (4 waves per SIMD on every CU) are in flight.
+constexpr int kAutoVariant = 14;
+constexpr uint32_t kTargetBlocks = 256;  // one 16-wave workgroup per CU
+constexpr uint32_t kMaxJSplit = 32;
 
 }  // namespace
 
@@ -323,14 +369,39 @@ const char *naive_variant_name(int v) {
     return (v >= 0 && v < kNumVariants) ? kVariants[v].name : "?";
 }
 
+NaivePlan plan_naive(uint32_t n, uint32_t n_local, int variant, int jsplit) {
+    NaivePlan p{};
+    p.variant = (variant >= 0 && variant < kNumVariants) ? variant : kAutoVariant;
+    const Variant &v = kVariants[p.variant];
+    const uint32_t itile = 64u * (uint32_t)v.ib;
+    p.blocks = n_local ? (n_local + itile - 1u) / itile : 0u;
+    const uint32_t n_tiles = (n + kJTile - 1u) / kJTile;
+    const uint32_t max_js = n_tiles / (uint32_t)v.w ? n_tiles / (uint32_t)v.w : 1u;  // >= 1 tile per wave
+    uint32_t js = 1;
+    if (jsplit > 0)
+        js = (uint32_t)jsplit;
+    else if (p.blocks && p.blocks < kTargetBlocks)
+        js = (kTargetBlocks + p.blocks - 1u) / p.blocks;
+    if (js > max_js) js = max_js;
+    if (js > kMaxJSplit) js = kMaxJSplit;
+    p.jsplit = js ? js : 1u;
+    return p;
+}
+
 hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream) {
     if (a.hi <= a.lo) return hipSuccess;  // a rank that owns no bodies
-    const int vi = (a.variant >= 0 && a.variant < kNumVariants) ? a.variant : auto_variant(a.hi - a.lo);
-    const Variant &v = kVariants[vi];
-    const uint32_t itile = 64u * (uint32_t)v.ib;
-    const uint32_t blocks = (a.hi - a.lo + itile - 1u) / itile;
-    hipLaunchKernelGGL(v.fn, dim3(blocks), dim3(64u * (uint32_t)v.w), 0, stream, a.posm_src,
-                       a.posm_dst, a.vel, a.acc, a.n, a.n_pad, a.lo, a.hi, a.g, a.e, a.dt);
+    const NaivePlan p = plan_naive(a.n, a.hi - a.lo, a.variant, a.jsplit);
+    const Variant &v = kVariants[p.variant];
+    if (p.jsplit > 1 && (!a.partial || a.partial_slices < p.jsplit)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(v.fn, dim3(p.blocks, p.jsplit), dim3(64u * (uint32_t)v.w), 0, stream,
+                       a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride, a.n,
+                       a.n_pad, a.lo, a.hi, a.g, a.e, a.dt);
+    if (p.jsplit > 1) {
+        const uint32_t nl = a.hi - a.lo;
+        hipLaunchKernelGGL(naive_finish_kernel, dim3((nl + 255u) / 256u), dim3(256), 0, stream,
+                           a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride,
+                           p.jsplit, a.lo, a.hi, a.g, a.dt);
+    }
     return hipGetLastError();
 }
 

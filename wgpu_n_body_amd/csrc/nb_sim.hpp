@@ -62,7 +62,10 @@ class NaiveSim final : public SimBase {
     float4 *vel = nullptr, *acc = nullptr;  // this rank's bodies only
     nb_particle *d_aos = nullptr;           // AoS staging for the 40-byte boundary layout
     int cur = 0;                            // posm[cur] holds the current state
-    int variant = -1;
+    int variant = -1, jsplit = 0;           // tuning overrides (<0 / 0 = automatic)
+    float4 *partial = nullptr;              // j-split partial sums [slices][per_rank]
+    uint32_t partial_slices = 0;
+    int ensure_workspace();
     std::vector<hipEvent_t> events;
 };
 
