@@ -16,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libnbody_hip.so")
+HEADLESS = os.path.join(PKG, "headless")
 ARCH = "gfx950"
 
 # (source, extra flags)
@@ -62,6 +63,15 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
     if force or _newer(LIB, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    # the C++ host mirror (simulator.hpp) + the headless CLI, plain g++ against the C ABI
+    cli_src = os.path.join(CSRC, "headless.cpp")
+    if force or _newer(HEADLESS, [cli_src, os.path.join(CSRC, "simulator.hpp"), LIB]):
+        cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", f"-I{INCLUDE}", f"-I{CSRC}",
+               cli_src, "-o", HEADLESS, f"-L{PKG}", "-lnbody_hip", f"-Wl,-rpath,{PKG}",
+               "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -1,0 +1,65 @@
+// headless.cpp -- C++ counterpart of the reference's src/bin/headless.rs:14-35 (and of the
+// criterion groups in benches/benchmark.rs:12-49) over the drop-in API of simulator.hpp.
+//
+//   headless [--sim naive|tree] [--n N] [--steps S] [--theta T] [--init uniform|disc|spherical]
+//            [--seed K] [--device D]
+//
+// Defaults reproduce headless.rs: TreeSim, 4,000,000 bodies, theta 0.75, uniform_init,
+// 10 steps, printing "Step Duration: {} us" per step.  (TreeSim needs the Barnes-Hut build;
+// pass --sim naive --n 65536 for the all-pairs path.)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "simulator.hpp"
+
+template <class Sim>
+static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbody::InitFn &init,
+               int steps, int device) {
+    std::puts("Initializing Simulation");
+    nbody::OfflineHeadless<Sim> runner(sp, ap, init, device);
+    std::puts("Running Simulation");
+    for (int i = 0; i < steps; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        runner.step();
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(
+                            std::chrono::steady_clock::now() - t0).count();
+        std::printf("Step Duration: %lld \xC2\xB5s\n", (long long)us);
+    }
+    std::puts("Finished Running");
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    std::string sim = "tree", init = "uniform";
+    nbody::SimParams sp{4000000u, 0.000001f, 0.0001f, 0.016f};  // headless.rs:15-20
+    float theta = 0.75f;
+    int steps = 10, device = -1;
+    uint64_t seed = 0;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        const std::string k = argv[i], v = argv[i + 1];
+        if (k == "--sim") sim = v;
+        else if (k == "--n") sp.particle_num = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (k == "--steps") steps = std::atoi(v.c_str());
+        else if (k == "--theta") theta = (float)std::atof(v.c_str());
+        else if (k == "--init") init = v;
+        else if (k == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10);
+        else if (k == "--device") device = std::atoi(v.c_str());
+        else if (k == "--g") sp.g = (float)std::atof(v.c_str());
+        else if (k == "--dt") sp.dt = (float)std::atof(v.c_str());
+        else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    const nbody::InitFn fn = init == "disc" ? nbody::inits::disc_init(seed)
+                           : init == "spherical" ? nbody::inits::spherical_init(seed)
+                                                 : nbody::inits::uniform_init(seed);
+    try {
+        if (sim == "naive")
+            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device);
+        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device);
+    } catch (const nbody::Error &e) {
+        std::fprintf(stderr, "error %d: %s\n", e.code(), e.what());
+        return 1;
+    }
+}
