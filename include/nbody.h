@@ -232,6 +232,11 @@ int nb_sim_set_tuning(nb_sim *sim, const char *key, int value);
 int nb_naive_variant_count(void);
 const char *nb_naive_variant_name(int variant);
 
+/* Testing hook: copy a named internal device buffer to the host (e.g. TreeSim "order": the
+ * source index of the body at each sorted position, u32 x N; "counters": walk visit/accept
+ * counts, u64 x 4; "status": u32 x 4).  *bytes receives the buffer's length. */
+int nb_sim_debug_buffer(nb_sim *sim, const char *name, void *dst, size_t cap, size_t *bytes);
+
 int nb_sim_destroy(nb_sim *sim);
 
 /* ------------------------------------------------------------------------- */

@@ -271,6 +271,15 @@ class Simulator:
     def set_tuning(self, key: str, value: int) -> None:
         check(_lib.lib().nb_sim_set_tuning(self._h, key.encode(), int(value)))
 
+    def debug_buffer(self, name: str, dtype) -> np.ndarray:
+        """Testing hook (nb_sim_debug_buffer): a named internal device buffer as a numpy array."""
+        nbytes = C.c_size_t()
+        check(_lib.lib().nb_sim_debug_buffer(self._h, name.encode(), None, 0, C.byref(nbytes)))
+        out = np.zeros(nbytes.value // np.dtype(dtype).itemsize, dtype=dtype)
+        check(_lib.lib().nb_sim_debug_buffer(self._h, name.encode(), out.ctypes.data, out.nbytes,
+                                             C.byref(nbytes)))
+        return out
+
     def read_tree(self):
         """TreeSim: (octants[n_nodes], root_width) of the tree the last step built."""
         n = self.sim_params().particle_num

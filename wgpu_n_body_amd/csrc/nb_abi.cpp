@@ -294,6 +294,10 @@ static int make_sim(nb_sim **out, const nb_sim_params *sp, const nb_add_params *
             set_error("TreeSim does not shard across ranks yet (replicas only)");
             return NB_ERR_UNSUPPORTED;
         }
+        if (pl && (pl->posm[0] || pl->posm[1])) {
+            set_error("TreeSim owns its buffers (placement.posm must be NULL)");
+            return NB_ERR_INVALID;
+        }
     } else {
         set_error("unknown add_params.kind %d", add.kind);
         return NB_ERR_INVALID;
@@ -446,6 +450,14 @@ int nb_sim_set_tuning(nb_sim *sim, const char *key, int value) {
         return NB_ERR_INVALID;
     }
     NB_SIM_CALL(sim, set_tuning(key, value))
+}
+
+int nb_sim_debug_buffer(nb_sim *sim, const char *name, void *dst, size_t cap, size_t *bytes) {
+    if (!name) {
+        set_error("null name");
+        return NB_ERR_INVALID;
+    }
+    NB_SIM_CALL(sim, debug_buffer(name, dst, cap, bytes))
 }
 
 int nb_naive_variant_count(void) { return naive_variant_count(); }

@@ -31,6 +31,10 @@ class SimBase {
         set_error("read_tree: not a TreeSim");
         return NB_ERR_UNSUPPORTED;
     }
+    virtual int debug_buffer(const char *name, void *, size_t, size_t *) {
+        set_error("unknown debug buffer '%s'", name);
+        return NB_ERR_INVALID;
+    }
     virtual int set_tuning(const char *key, int) {
         set_error("unknown tuning key '%s'", key);
         return NB_ERR_INVALID;
