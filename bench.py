@@ -101,9 +101,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available() or nb.device_count() == 0:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    # Rehearsal knobs (tests only): NB_DIST_BACKEND=gloo and NB_BENCH_SAME_DEVICE=1 let several
+    # ranks share one GPU, which RCCL refuses; the driver's runs use neither.
+    backend = os.environ.get("NB_DIST_BACKEND", "nccl")
+    if os.environ.get("NB_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.bodies
     sp = nb.SimParams(particle_num=n, g=G, e=E, dt=DT)

@@ -167,8 +167,9 @@ def test_runner_matches_simulator_and_write_read_roundtrip(gpu):
     init = nb.inits.spherical_init(sp, seed=5)
     runner = nb.OfflineHeadless(nb.NaiveSim, sp, nb.AddParams.NaiveSimParams(),
                                 lambda p: nb.inits.spherical_init(p, seed=5))
-    assert runner.sim_params() == nb.SimParams(777, np.float32(sp.g), np.float32(sp.e),
-                                               np.float32(sp.dt)) or True
+    got_sp = runner.sim_params()
+    assert got_sp.particle_num == 777 and np.float32(got_sp.g) == np.float32(sp.g) \
+        and np.float32(got_sp.e) == np.float32(sp.e) and np.float32(got_sp.dt) == np.float32(sp.dt)
     assert np.array_equal(runner.read_particles(), init)      # state 0 == init, bit for bit
     runner.step()
     runner.step_n(2)
@@ -299,3 +300,41 @@ def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world, jsplit):
         assert not got[:lo, 3:9].any() and not got[hi:, 3:9].any()
         s.destroy()
     single.destroy()
+
+
+def test_sharded_naive_sim_two_ranks_one_gpu(gpu, tmp_path):
+    """The product's multi-GPU class (ShardedNaiveSim: torch-owned position buffers, kernels on
+    torch's stream, in-place all_gather_into_tensor) run as 2 processes sharing this one GPU,
+    gloo standing in for RCCL; must equal the single simulator bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    nb = gpu
+    n, steps, world = 3000, 3, 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
+             str(n), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode(errors="replace")[-3000:]
+    sp = nb.SimParams(particle_num=n)
+    single = nb.NaiveSim.from_particles(sp, None, nb.inits.uniform_init(sp, seed=77))
+    single.set_tuning("naive_variant", 1)
+    single.set_tuning("naive_jsplit", 1)
+    for _ in range(steps):
+        single.encode()
+    want = nb.as_floats(single.dest_particle_slice())
+    single.destroy()
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"gpu_rank{rank}.npz"))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        assert np.array_equal(bits(z["state"][:, [0, 1, 2, 9]]), bits(want[:, [0, 1, 2, 9]]))
+        assert np.array_equal(bits(z["state"][lo:hi]), bits(want[lo:hi]))
