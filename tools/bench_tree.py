@@ -1,0 +1,46 @@
+"""Barnes-Hut step benchmark (BASELINE.json configs[2]: 1,048,576 bodies, theta 0.5, 1 GPU).
+Prints one JSON line: ms/step, walk-kernel ms, bodies/s, counted node visits/s.  Secondary to
+bench.py (the headline all-pairs metric); used for profiles/ and DESIGN.md."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wgpu_n_body_amd as nb  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bodies", type=int, default=1 << 20)
+ap.add_argument("--theta", type=float, default=0.5)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--init", default="uniform")
+ap.add_argument("--seed", type=int, default=3)
+args = ap.parse_args()
+
+sp = nb.SimParams(particle_num=args.bodies)
+init = getattr(nb.inits, args.init + "_init")(sp, seed=args.seed)
+sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(args.theta), init)
+sim.set_tuning("tree_count_visits", 1)
+sim.encode(); sim.wait()
+c0 = sim.debug_buffer("counters", np.uint64).copy()
+sim.set_tuning("tree_count_visits", 0)
+for _ in range(args.warmup):
+    sim.encode()
+sim.wait()
+t0 = time.perf_counter()
+tot, walk = sim.encode_n_timed(args.steps)
+wall = time.perf_counter() - t0
+tree, rw = sim.read_tree()
+out = nb.as_floats(sim.dest_particle_slice())
+assert np.isfinite(out).all()
+print(json.dumps({
+    "metric": "Barnes-Hut step", "bodies": args.bodies, "theta": args.theta, "init": args.init,
+    "ms_per_step": wall / args.steps * 1e3, "ms_per_step_events": tot / args.steps,
+    "walk_kernel_ms": walk, "build_ms": tot / args.steps - walk,
+    "bodies_per_s": args.bodies * args.steps / wall, "nodes": int(len(tree)),
+    "visits_per_body_step1": float(c0[0]) / args.bodies, "accepted_per_body_step1": float(c0[1]) / args.bodies,
+    "lane_visits_per_s": float(c0[0]) / (walk * 1e-3), "steps": args.steps, "warmup": args.warmup}))

@@ -50,7 +50,7 @@ constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
 constexpr uint32_t kIdThreads = 256;
-constexpr uint32_t kWalkStack = 256;   // wave-level stack entries (16 B each)
+constexpr uint32_t kWalkStack = 384;   // wave-level stack entries (16 B each)
 
 __device__ __forceinline__ float kick(float v, float a, float dt) {
 #pragma clang fp contract(off)
@@ -417,7 +417,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ leaf_id, const uint32_t *__restrict__ int_id,
                             const uint32_t *__restrict__ order, const float4 *__restrict__ posm,
                             float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
-                            uint32_t *__restrict__ child) {
+                            uint32_t *__restrict__ child, uint2 *__restrict__ link) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     if (id >= n_nodes) return;
@@ -428,6 +428,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         cogm[id] = posm[k];
         bodies[id] = 1;
         ch[0] = order[k];  // tree.rs:532
+        link[id] = uint2{k, 0u};  // walk: a leaf knows its body's sorted position
     } else {
         const uint32_t d = dd;
         const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
@@ -449,6 +450,12 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             b = e;
         }
         cogm[id] = float4{0.f, 0.f, 0.f, 0.f};
+        // children are allocated contiguously in octant order (tree.rs:517-519), so the walk
+        // only needs the first child's id and how many there are
+        uint32_t first = 0, cnt = 0;
+        for (int c = 7; c >= 0; --c)
+            if (ch[c]) { first = ch[c]; ++cnt; }
+        link[id] = uint2{first, cnt};
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
@@ -475,97 +482,131 @@ __global__ void level_mass_kernel(const uint32_t *__restrict__ depth_base, int d
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
+// Stack entry: cell id (27 bits) | depth << 27, and the 64-bit mask of lanes that visit it.
 struct StackEntry {
-    uint32_t node;
-    uint32_t depth;
-    uint64_t mask;
+    uint32_t node_depth;
+    uint32_t mask_lo, mask_hi;
+    uint32_t pad;
 };
+constexpr uint32_t kWalkBatch = 4;  // cells popped (and fetched) together per iteration
+constexpr uint32_t kNodeBits = 27;  // 2^27 cells: 4N nodes for up to 33 M bodies
 
+// One cell against the wave's 64 bodies.  Returns the lanes that must open it.
+// Acceptance test size/dist < theta (tree.wgsl:63-64) in squared form, size^2 < theta^2 r^2:
+// no sqrt or reciprocal unless some lane accumulates the cell.
+template <bool COUNT>
+__device__ __forceinline__ uint64_t visit_cell(const float4 q, const uint2 lk, uint32_t depth,
+                                               bool mine, uint32_t my_pos, float xi, float yi,
+                                               float zi, float root_width, float theta2, float e,
+                                               float &ax, float &ay, float &az,
+                                               unsigned long long &visits,
+                                               unsigned long long &accepts) {
+    // size_stack: root_width halved `depth` times (exact: a power-of-two scaling, tree.wgsl:82)
+    const float size = root_width * __uint_as_float((127u - depth) << 23);
+    const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
+    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    bool take;
+    uint64_t open = 0;
+    if (lk.y == 0u) {  // a leaf is a body: always accumulate, except the body itself
+        take = mine && lk.x != my_pos;
+    } else {
+        const bool far = size * size < theta2 * r2;
+        take = mine && far;
+        open = __ballot(mine && !far);
+    }
+    if (take) {
+        const float dist = __builtin_amdgcn_sqrtf(r2);
+        const float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
+        ax = __builtin_fmaf(w, dx, ax);
+        ay = __builtin_fmaf(w, dy, ay);
+        az = __builtin_fmaf(w, dz, az);
+    }
+    if (COUNT) {
+        visits += mine ? 1ull : 0ull;
+        accepts += take ? 1ull : 0ull;
+    }
+    return open;
+}
+
+template <bool COUNT>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
-    const float4 *__restrict__ acc_src, const uint32_t *__restrict__ order,
-    const float4 *__restrict__ cogm, const uint32_t *__restrict__ bodies,
-    const uint32_t *__restrict__ child, const uint32_t *__restrict__ bound_bits,
+    const float4 *__restrict__ acc_src, const float4 *__restrict__ cogm,
+    const uint2 *__restrict__ link, const uint32_t *__restrict__ bound_bits,
     const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, float4 *__restrict__ posm_dst,
     float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst, uint32_t n, float g, float e,
     float dt, float theta, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const uint32_t ic = valid ? i : n - 1;
     const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
-    const uint32_t self_src = order[ic];
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
     float ax = 0.f, ay = 0.f, az = 0.f;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     const float root_width = __uint_as_float(*bound_bits) * 2.0f;
-    const uint64_t lane_bit = 1ull << (threadIdx.x & 63);
+    const float theta2 = theta * theta;
+    const uint32_t lane_lo = lane < 32u ? 1u << lane : 0u, lane_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
     unsigned long long visits = 0, accepts = 0;
 
     StackEntry *stack = s_stack[wave];
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
     if (n >= 2 && all) {
-        if ((threadIdx.x & 63) == 0) stack[0] = StackEntry{0u, 0u, all};
+        if (lane == 0) stack[0] = StackEntry{0u, (uint32_t)all, (uint32_t)(all >> 32), 0u};
         sp = 1;
     }
     __builtin_amdgcn_wave_barrier();
     // every cell is pushed at most once per wave; the bound makes a corrupt tree exit, not hang
     uint32_t budget = 2u * n_nodes + 64u;
     while (sp > 0) {
-        if (--budget == 0u) {
-            if ((threadIdx.x & 63) == 0) atomicAdd(&status[3], 1u);
+        // pop up to kWalkBatch cells and fetch them together: their (wave-uniform, scalar)
+        // loads overlap instead of forming one dependent chain per cell
+        const uint32_t nb = sp < kWalkBatch ? sp : kWalkBatch;
+        if (budget <= nb) {
+            if (lane == 0) atomicAdd(&status[3], 1u);
             break;
         }
-        --sp;
-        const StackEntry top = stack[sp];  // wave-uniform
-        const uint32_t node = __builtin_amdgcn_readfirstlane(top.node);
-        const uint32_t depth = __builtin_amdgcn_readfirstlane(top.depth);
-        // (the builtin returns a signed int: go through uint32_t or the low half sign-extends)
-        const uint32_t mask_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)top.mask);
-        const uint32_t mask_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(top.mask >> 32));
-        const uint64_t mask = ((uint64_t)mask_hi << 32) | (uint64_t)mask_lo;
-        const float4 q = cogm[node];
-        const uint32_t nb_bodies = __builtin_amdgcn_readfirstlane(bodies[node]);
-        const bool mine = (mask & lane_bit) != 0;
-        // size_stack: root_width halved `depth` times (exact: a power-of-two scaling)
-        const float size = root_width * __uint_as_float((127u - depth) << 23);
-        const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
-        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float dist = __builtin_amdgcn_sqrtf(r2);
-        bool take;
-        uint64_t open = 0;
-        if (nb_bodies == 1u) {  // a leaf is a body: always accumulate, except the body itself
-            const uint32_t leaf_src = child[(size_t)node * 8];
-            take = mine && leaf_src != self_src;
-        } else {
-            const float sd = size / dist;  // tree.wgsl:63
-            take = mine && sd < theta;
-            open = __ballot(mine && !(sd < theta));
+        budget -= nb;
+        sp -= nb;
+        uint32_t e_node[kWalkBatch], e_depth[kWalkBatch], e_lo[kWalkBatch], e_hi[kWalkBatch];
+        float4 q[kWalkBatch];
+        uint2 lk[kWalkBatch];
+#pragma unroll
+        for (uint32_t b = 0; b < kWalkBatch; ++b) {
+            const StackEntry t = stack[sp + (b < nb ? nb - 1u - b : 0u)];  // b = 0 is the old top
+            // (the builtin returns a signed int: go through uint32_t or values sign-extend)
+            const uint32_t nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.node_depth);
+            e_node[b] = nd & ((1u << kNodeBits) - 1u);
+            e_depth[b] = nd >> kNodeBits;
+            e_lo[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask_lo);
+            e_hi[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask_hi);
         }
-        if (take) {
-            const float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-            ax = __builtin_fmaf(w, dx, ax);
-            ay = __builtin_fmaf(w, dy, ay);
-            az = __builtin_fmaf(w, dz, az);
+#pragma unroll
+        for (uint32_t b = 0; b < kWalkBatch; ++b) {
+            q[b] = cogm[e_node[b]];
+            lk[b] = link[e_node[b]];
         }
-        visits += mine ? 1ull : 0ull;
-        accepts += take ? 1ull : 0ull;
-        if (open) {  // push the existing children 0..7 for the lanes that opened the node
-            uint32_t c_id = 0;
-            if ((threadIdx.x & 63) < 8) c_id = child[(size_t)node * 8 + (threadIdx.x & 63)];
-            const uint64_t have = __ballot(c_id != 0u && c_id < n_nodes) & 0xffull;
-            const uint32_t cnt = (uint32_t)__popcll(have);
-            if (sp + cnt > kWalkStack) {
-                if ((threadIdx.x & 63) == 0) atomicAdd(&status[0], 1u);
-            } else {
-                if (have & lane_bit) {
-                    const uint32_t slot = sp + (uint32_t)__popcll(have & (lane_bit - 1ull));
-                    stack[slot] = StackEntry{c_id, depth + 1u, open};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t b = 0; b < kWalkBatch; ++b) {
+            if (b >= nb) break;
+            const bool mine = ((e_lo[b] & lane_lo) | (e_hi[b] & lane_hi)) != 0u;
+            const uint64_t open = visit_cell<COUNT>(q[b], lk[b], e_depth[b], mine, i, xi, yi, zi,
+                                                    root_width, theta2, e, ax, ay, az, visits, accepts);
+            if (open) {  // push the children (contiguous ids, octant order) for the opening lanes
+                const uint32_t cnt = lk[b].y, first = lk[b].x;
+                if (sp + cnt > kWalkStack || first + cnt > n_nodes) {
+                    if (lane == 0) atomicAdd(&status[0], 1u);
+                } else {
+                    if (lane < cnt)
+                        stack[sp + lane] = StackEntry{(first + lane) | ((e_depth[b] + 1u) << kNodeBits),
+                                                      (uint32_t)open, (uint32_t)(open >> 32), 0u};
+                    sp += cnt;
                 }
-                sp += cnt;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -576,7 +617,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     posm_dst[i] = float4{xi, yi, zi, p.w};
     vel_dst[i] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
     acc_dst[i] = float4{fx, fy, fz, 0.f};
-    if (counters) {
+    if (COUNT) {
         atomicAdd(&counters[0], visits);
         atomicAdd(&counters[1], accepts);
     }
@@ -626,7 +667,7 @@ class TreeSim final : public SimBase {
         }
         theta = add.theta > 0.f ? add.theta : NB_DEFAULT_THETA;
         const size_t nn = n ? n : 1;
-        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
+        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, (1u << kNodeBits) - 1u);  // 4N as tree.rs:188-190
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
         id_blocks = (uint32_t)((nn + kIdThreads - 1) / kIdThreads);
         scan_blocks = (uint32_t)((nn + kScanTile - 1) / kScanTile);
@@ -654,6 +695,7 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&node_first, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_depth, (size_t)node_cap)) return rc;
         if (int rc = alloc(&cogm, sizeof(float4) * (size_t)node_cap)) return rc;
+        if (int rc = alloc(&link, sizeof(uint2) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&bodies, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
         if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
@@ -733,16 +775,20 @@ class TreeSim final : public SimBase {
         const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d], cogm,
-                           bodies, child);
+                           bodies, child, link);
         for (int depth = kLevels; depth >= 0; --depth)
             hipLaunchKernelGGL(level_mass_kernel, dim3(level_blocks(depth)), b256, 0, stream, depth_base,
                                depth, node_cap, bodies, child, cogm);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
-        hipLaunchKernelGGL(walk_kernel, dim3(g256), b256, 0, stream, posm[d], vel[d], acc[d], order, cogm,
-                           bodies, child, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n,
-                           params.g, params.e, params.dt, theta, status,
-                           count_visits ? counters : (unsigned long long *)nullptr);
+        if (count_visits)
+            hipLaunchKernelGGL(walk_kernel<true>, dim3(g256), b256, 0, stream, posm[d], vel[d], acc[d], cogm,
+                               link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, params.g,
+                               params.e, params.dt, theta, status, counters);
+        else
+            hipLaunchKernelGGL(walk_kernel<false>, dim3(g256), b256, 0, stream, posm[d], vel[d], acc[d], cogm,
+                               link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, params.g,
+                               params.e, params.dt, theta, status, counters);
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
         NB_HIP_TRY(hipGetLastError());
         // the post-step state is in buffer s (= cur); buffer d holds the sorted source
@@ -897,6 +943,7 @@ class TreeSim final : public SimBase {
     uint8_t *node_depth = nullptr;
     int8_t *cpl = nullptr;
     float4 *cogm = nullptr;
+    uint2 *link = nullptr;  // per node {first child id, child count} / leaf {sorted position, 0}
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false;
