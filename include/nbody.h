@@ -215,6 +215,15 @@ int nb_sim_read_tree(nb_sim *sim, nb_octant *dst, size_t cap, size_t *n_nodes, f
 int nb_sim_exchange_region(nb_sim *sim, void **dev_ptr, size_t *offset_bytes, size_t *slice_bytes,
                            size_t *total_bytes);
 
+/* Same, for simulators with several regions to exchange.  NaiveSim has one (positions/masses).
+ * A sharded TreeSim (replicated tree, partitioned walk: every rank builds the identical octree
+ * from the full state and walks only its range of the sorted bodies) has three: the new
+ * positions/masses, velocities and accelerations of its range -- the next step re-sorts all
+ * bodies, so all three must reach every rank.  index in [0, count). */
+int nb_sim_exchange_count(nb_sim *sim, int *count);
+int nb_sim_exchange_region_i(nb_sim *sim, int index, void **dev_ptr, size_t *offset_bytes,
+                             size_t *slice_bytes, size_t *total_bytes);
+
 /* Step counter (`step_num`, src/sims/naive.rs:160). */
 int nb_sim_step_num(const nb_sim *sim, uint64_t *out);
 

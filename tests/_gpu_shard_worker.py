@@ -1,7 +1,8 @@
 """Worker for tests/test_naive_gpu.py::test_sharded_naive_sim_two_ranks_one_gpu: one rank of a
 2-process run of the PRODUCT sharded path (wgpu_n_body_amd.sharded.ShardedNaiveSim: HIP local
 step + in-place all-gather through torch.distributed) with both ranks on cuda:0 and the gloo
-backend standing in for RCCL (RCCL refuses two ranks on one device).  argv: out_dir n steps"""
+backend standing in for RCCL (RCCL refuses two ranks on one device).
+argv: out_dir n steps [naive|tree]"""
 import os
 import sys
 
@@ -13,18 +14,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import wgpu_n_body_amd as nb  # noqa: E402
-from wgpu_n_body_amd.sharded import ShardedNaiveSim  # noqa: E402
+from wgpu_n_body_amd.sharded import ShardedNaiveSim, ShardedTreeSim  # noqa: E402
 
 
 def main():
     out_dir, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    mode = sys.argv[4] if len(sys.argv) > 4 else "naive"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     sp = nb.SimParams(particle_num=n)
     init = nb.inits.uniform_init(sp, seed=77)
-    sim = ShardedNaiveSim(sp, init, rank, world, 0, variant=1)
-    sim.sim.set_tuning("naive_jsplit", 1)
+    if mode == "tree":
+        sim = ShardedTreeSim(sp, 0.5, init, rank, world, 0)
+        sim.lo, sim.hi = 0, n
+    else:
+        sim = ShardedNaiveSim(sp, init, rank, world, 0, variant=1)
+        sim.sim.set_tuning("naive_jsplit", 1)
     for _ in range(steps):
         sim.encode()
         sim.cleanup()

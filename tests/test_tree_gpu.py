@@ -213,3 +213,39 @@ def test_full_size_tree_invariants_and_sampled_walk(gpu, oracle):
     assert np.array_equal(ref_tree["bodies"], tree["bodies"])
     assert np.array_equal(ref_tree["children"], tree["children"])
     assert np.array_equal(oracle.tree_dfs_order(ref_tree, n), order)
+
+
+@pytest.mark.parametrize("n,world", [(5000, 2), (3000, 3)])
+def test_sharded_tree_sim_ranks_on_one_gpu(gpu, tmp_path, n, world):
+    """Multi-GPU Barnes-Hut, step 1 of SURVEY 8(e): replicated tree, partitioned walk, three
+    in-place all-gathers (ShardedTreeSim).  `world` processes share this one GPU with gloo
+    standing in for RCCL; every rank must end with the single simulator's state, bit for bit."""
+    import socket
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    nb = gpu
+    steps = 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
+             str(n), str(steps), "tree"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode(errors="replace")[-3000:]
+    sp = nb.SimParams(particle_num=n)
+    single = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5),
+                                       nb.inits.uniform_init(sp, seed=77))
+    for _ in range(steps):
+        single.encode()
+    want = nb.as_floats(single.dest_particle_slice())
+    single.destroy()
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"gpu_rank{rank}.npz"))
+        assert np.array_equal(bits(z["state"]), bits(want)), rank

@@ -261,12 +261,17 @@ class Simulator:
         check(_lib.lib().nb_sim_encode_n_timed(self._h, n, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
-    def exchange_region(self):
-        """(device_ptr, offset_bytes, slice_bytes, total_bytes) of the buffer just written."""
+    def exchange_region(self, index: int = 0):
+        """(device_ptr, offset_bytes, slice_bytes, total_bytes) of exchange region `index`."""
         p, o, s, t = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
-        check(_lib.lib().nb_sim_exchange_region(self._h, C.byref(p), C.byref(o), C.byref(s),
-                                                C.byref(t)))
+        check(_lib.lib().nb_sim_exchange_region_i(self._h, int(index), C.byref(p), C.byref(o),
+                                                  C.byref(s), C.byref(t)))
         return int(p.value or 0), int(o.value), int(s.value), int(t.value)
+
+    def exchange_count(self) -> int:
+        c = C.c_int()
+        check(_lib.lib().nb_sim_exchange_count(self._h, C.byref(c)))
+        return int(c.value)
 
     def set_tuning(self, key: str, value: int) -> None:
         check(_lib.lib().nb_sim_set_tuning(self._h, key.encode(), int(value)))

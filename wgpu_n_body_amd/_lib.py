@@ -51,7 +51,8 @@ ABI_SYMBOLS = [
     "nb_shard_bodies_per_rank", "nb_shard_padded_bodies",
     "nb_sim_create", "nb_sim_create_from_particles", "nb_sim_encode", "nb_sim_cleanup",
     "nb_sim_wait", "nb_sim_sim_params", "nb_sim_read_particles", "nb_sim_write_particles",
-    "nb_sim_read_tree", "nb_sim_exchange_region", "nb_sim_step_num", "nb_sim_encode_n_timed",
+    "nb_sim_read_tree", "nb_sim_exchange_region", "nb_sim_exchange_count",
+    "nb_sim_exchange_region_i", "nb_sim_step_num", "nb_sim_encode_n_timed",
     "nb_sim_set_tuning", "nb_sim_debug_buffer", "nb_naive_variant_count", "nb_naive_variant_name", "nb_sim_destroy",
     "nb_runner_create", "nb_runner_step", "nb_runner_step_n", "nb_runner_read_particles",
     "nb_runner_sim_params", "nb_runner_sim", "nb_runner_destroy",
@@ -100,6 +101,8 @@ def lib() -> C.CDLL:
     L.nb_sim_write_particles.argtypes = [vp, vp, sz]
     L.nb_sim_read_tree.argtypes = [vp, vp, sz, P(sz), P(C.c_float)]
     L.nb_sim_exchange_region.argtypes = [vp, P(vp), P(sz), P(sz), P(sz)]
+    L.nb_sim_exchange_count.argtypes = [vp, P(C.c_int)]
+    L.nb_sim_exchange_region_i.argtypes = [vp, C.c_int, P(vp), P(sz), P(sz), P(sz)]
     L.nb_sim_step_num.argtypes = [vp, P(u64)]
     L.nb_sim_encode_n_timed.argtypes = [vp, C.c_int, P(C.c_float), P(C.c_float)]
     L.nb_sim_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]

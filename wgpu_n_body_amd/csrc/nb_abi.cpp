@@ -242,7 +242,11 @@ int NaiveSim::read_particles(nb_particle *dst, size_t count) {
     return NB_OK;
 }
 
-int NaiveSim::exchange_region(void **dev_ptr, size_t *off, size_t *len, size_t *total) {
+int NaiveSim::exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) {
+    if (index != 0) {
+        set_error("exchange region %d out of range (NaiveSim has 1)", index);
+        return NB_ERR_INVALID;
+    }
     if (dev_ptr) *dev_ptr = posm[cur];
     if (off) *off = sizeof(float4) * (size_t)per_rank * (size_t)place.rank;
     if (len) *len = sizeof(float4) * (size_t)per_rank;
@@ -290,10 +294,6 @@ static int make_sim(nb_sim **out, const nb_sim_params *sp, const nb_add_params *
             return NB_ERR_UNSUPPORTED;
         }
         if (!(add.theta > 0.f)) add.theta = NB_DEFAULT_THETA;  // tree.rs:42-51
-        if (pl && pl->world > 1) {
-            set_error("TreeSim does not shard across ranks yet (replicas only)");
-            return NB_ERR_UNSUPPORTED;
-        }
         if (pl && (pl->posm[0] || pl->posm[1])) {
             set_error("TreeSim owns its buffers (placement.posm must be NULL)");
             return NB_ERR_INVALID;
@@ -428,7 +428,21 @@ int nb_sim_read_tree(nb_sim *sim, nb_octant *dst, size_t cap, size_t *n_nodes, f
 
 int nb_sim_exchange_region(nb_sim *sim, void **dev_ptr, size_t *offset_bytes, size_t *slice_bytes,
                            size_t *total_bytes) {
-    NB_SIM_CALL(sim, exchange_region(dev_ptr, offset_bytes, slice_bytes, total_bytes))
+    NB_SIM_CALL(sim, exchange_region(0, dev_ptr, offset_bytes, slice_bytes, total_bytes))
+}
+
+int nb_sim_exchange_count(nb_sim *sim, int *count) {
+    if (!sim || !sim->impl || !count) {
+        set_error("null argument");
+        return NB_ERR_INVALID;
+    }
+    *count = sim->impl->exchange_count();
+    return NB_OK;
+}
+
+int nb_sim_exchange_region_i(nb_sim *sim, int index, void **dev_ptr, size_t *offset_bytes,
+                             size_t *slice_bytes, size_t *total_bytes) {
+    NB_SIM_CALL(sim, exchange_region(index, dev_ptr, offset_bytes, slice_bytes, total_bytes))
 }
 
 int nb_sim_step_num(const nb_sim *sim, uint64_t *out) {

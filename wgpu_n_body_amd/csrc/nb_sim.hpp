@@ -23,7 +23,8 @@ class SimBase {
     virtual int read_particles(nb_particle *dst, size_t count) = 0;       // dest_particle_slice
     virtual int write_particles(const nb_particle *src, size_t count) = 0;
     virtual int encode_n_timed(int count, float *ms_total, float *ms_kernel) = 0;
-    virtual int exchange_region(void **, size_t *, size_t *, size_t *) {
+    virtual int exchange_count() { return 0; }
+    virtual int exchange_region(int, void **, size_t *, size_t *, size_t *) {
         set_error("this simulator has no exchange region");
         return NB_ERR_UNSUPPORTED;
     }
@@ -57,7 +58,8 @@ class NaiveSim final : public SimBase {
     int read_particles(nb_particle *dst, size_t count) override;
     int write_particles(const nb_particle *src, size_t count) override;
     int encode_n_timed(int count, float *ms_total, float *ms_kernel) override;
-    int exchange_region(void **dev_ptr, size_t *off, size_t *len, size_t *total) override;
+    int exchange_count() override { return 1; }
+    int exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) override;
     int set_tuning(const char *key, int value) override;
 
    private:

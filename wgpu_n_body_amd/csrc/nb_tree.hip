@@ -534,14 +534,16 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ acc_src, const float4 *__restrict__ cogm,
     const uint2 *__restrict__ link, const uint32_t *__restrict__ bound_bits,
     const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, float4 *__restrict__ posm_dst,
-    float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst, uint32_t n, float g, float e,
-    float dt, float theta, uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
+    float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst, uint32_t n, uint32_t lo, uint32_t hi,
+    float g, float e, float dt, float theta, uint32_t *__restrict__ status,
+    unsigned long long *__restrict__ counters) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n;
-    const uint32_t ic = valid ? i : n - 1;
+    // this rank walks for the sorted bodies [lo, hi) (single GPU: [0, n))
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < hi;
+    const uint32_t ic = valid ? i : hi - 1;
     const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
@@ -675,10 +677,14 @@ class TreeSim final : public SimBase {
             set_error("TreeSim supports at most %u bodies", kScanTile * kScanTile);
             return NB_ERR_UNSUPPORTED;
         }
+        const size_t npad = n_pad ? n_pad : 256;  // equal-sized slices for the all-gathers
         for (int b = 0; b < 2; ++b) {
-            if (int rc = alloc(&posm[b], sizeof(float4) * nn)) return rc;
-            if (int rc = alloc(&vel[b], sizeof(float4) * nn)) return rc;
-            if (int rc = alloc(&acc[b], sizeof(float4) * nn)) return rc;
+            if (int rc = alloc(&posm[b], sizeof(float4) * npad)) return rc;
+            if (int rc = alloc(&vel[b], sizeof(float4) * npad)) return rc;
+            if (int rc = alloc(&acc[b], sizeof(float4) * npad)) return rc;
+            NB_HIP_TRY(hipMemsetAsync(posm[b], 0, sizeof(float4) * npad, stream));
+            NB_HIP_TRY(hipMemsetAsync(vel[b], 0, sizeof(float4) * npad, stream));
+            NB_HIP_TRY(hipMemsetAsync(acc[b], 0, sizeof(float4) * npad, stream));
             if (int rc = alloc(&keys[b], sizeof(uint64_t) * nn)) return rc;
             if (int rc = alloc(&idx[b], sizeof(uint32_t) * nn)) return rc;
         }
@@ -781,14 +787,17 @@ class TreeSim final : public SimBase {
                                depth, node_cap, bodies, child, cogm);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
-        if (count_visits)
-            hipLaunchKernelGGL(walk_kernel<true>, dim3(g256), b256, 0, stream, posm[d], vel[d], acc[d], cogm,
-                               link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, params.g,
-                               params.e, params.dt, theta, status, counters);
-        else
-            hipLaunchKernelGGL(walk_kernel<false>, dim3(g256), b256, 0, stream, posm[d], vel[d], acc[d], cogm,
-                               link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, params.g,
-                               params.e, params.dt, theta, status, counters);
+        if (hi > lo) {
+            const dim3 gwalk((hi - lo + 255) / 256);
+            if (count_visits)
+                hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], cogm,
+                                   link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   params.g, params.e, params.dt, theta, status, counters);
+            else
+                hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], cogm,
+                                   link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   params.g, params.e, params.dt, theta, status, counters);
+        }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
         NB_HIP_TRY(hipGetLastError());
         // the post-step state is in buffer s (= cur); buffer d holds the sorted source
@@ -889,6 +898,22 @@ class TreeSim final : public SimBase {
         }
         if (ms_total) *ms_total = total;
         if (ms_kernel) *ms_kernel = walk_sum / (float)count;  // the dominant kernel: the walk
+        return NB_OK;
+    }
+
+    // Sharded TreeSim = replicated tree, partitioned walk: after encode the
+    // rank's range of the three state arrays is new; the caller all-gathers each in place.
+    int exchange_count() override { return 3; }
+    int exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) override {
+        if (index < 0 || index > 2) {
+            set_error("exchange region %d out of range (TreeSim has 3)", index);
+            return NB_ERR_INVALID;
+        }
+        float4 *base = index == 0 ? posm[cur] : index == 1 ? vel[cur] : acc[cur];
+        if (dev_ptr) *dev_ptr = base;
+        if (off) *off = sizeof(float4) * (size_t)per_rank * (size_t)place.rank;
+        if (len) *len = sizeof(float4) * (size_t)per_rank;
+        if (total) *total = sizeof(float4) * (size_t)n_pad;
         return NB_OK;
     }
 

@@ -21,7 +21,8 @@ from typing import Optional
 
 import numpy as np
 
-from . import NaiveSim, Placement, SimParams, as_particles, shard_bodies_per_rank
+from . import (AddParams, NaiveSim, Placement, SimParams, TreeSim, as_particles,
+               shard_bodies_per_rank)
 
 
 @dataclass(frozen=True)
@@ -133,4 +134,68 @@ class ShardedNaiveSim(ShardedStepper):
         return self.sim.dest_particle_slice()
 
     def destroy(self) -> None:
+        self.sim.destroy()
+
+
+class _DevicePtr:
+    """Expose library-owned device memory to torch (zero-copy) via __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, nfloats: int):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4",
+                                         "data": (ptr, False), "version": 3, "strides": None}
+
+
+class ShardedTreeSim:
+    """Barnes-Hut on several GPUs, SURVEY 8(e) step 1: replicated tree, partitioned walk.
+
+    Every rank holds the full state, builds the identical octree (the build is deterministic)
+    and walks only its contiguous range of the SORTED bodies; then the range's new positions,
+    velocities and accelerations are all-gathered in place (three collectives: the next step
+    re-sorts all bodies, so all three arrays must be complete everywhere).  The tree build is
+    not sped up by more GPUs -- the spatial domain decomposition + LET exchange of the north
+    star is the next step."""
+
+    def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
+                 device_index: int, group=None):
+        import torch
+        self._torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self._dev = torch.device("cuda", device_index)
+        self.stream = torch.cuda.Stream(self._dev)
+        self.sim = TreeSim.from_particles(
+            sim_params, AddParams.TreeSimParams(theta), as_particles(particles),
+            Placement(device_index, rank, world, self.stream.cuda_stream))
+        self._views = {}
+        self.step_num = 0
+
+    def _view(self, ptr: int, total_bytes: int):
+        t = self._views.get(ptr)
+        if t is None:
+            t = self._torch.as_tensor(_DevicePtr(ptr, total_bytes // 4), device=self._dev)
+            self._views[ptr] = t
+        return t
+
+    def encode(self) -> None:
+        import torch.distributed as dist
+        with self._torch.cuda.stream(self.stream):
+            self.sim.encode()
+            if self.world > 1:
+                for k in range(self.sim.exchange_count()):
+                    ptr, off, ln, tot = self.sim.exchange_region(k)
+                    full = self._view(ptr, tot)
+                    dist.all_gather_into_tensor(full, full[off // 4:(off + ln) // 4], group=self.group)
+        self.step_num += 1
+
+    def cleanup(self) -> None:
+        self.sim.cleanup()
+
+    def wait(self) -> None:
+        self.stream.synchronize()
+
+    def read_particles(self) -> np.ndarray:
+        self._torch.cuda.synchronize(self._dev)
+        return self.sim.dest_particle_slice()
+
+    def destroy(self) -> None:
+        self._views.clear()
         self.sim.destroy()
