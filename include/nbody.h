@@ -177,6 +177,17 @@ int nb_sim_create_from_particles(nb_sim **out, const nb_sim_params *sim_params,
  * (naive.rs:156,160). */
 int nb_sim_encode(nb_sim *sim);
 
+/* The same step in two halves, so that a multi-GPU caller can overlap the exchange of step k
+ * with the beginning of step k+1 (all-pairs simulators with world > 1; otherwise phase 0 is a
+ * no-op and phase 1 is nb_sim_encode):
+ *   phase 0 -- interactions with the rank's OWN bodies.  Needs only this rank's slice of the
+ *              current positions, so it may be enqueued right after the previous step, while
+ *              the all-gather of the other slices is still in flight;
+ *   phase 1 -- interactions with everybody else's bodies (enqueue after the exchange has been
+ *              ordered on the stream), then the integrator; flips the ping-pong.
+ * nb_sim_encode after a phase 0 completes that step (= phase 1). */
+int nb_sim_encode_phase(nb_sim *sim, int phase);
+
 /* `Simulator::cleanup(&mut self)`, src/sims/mod.rs:87-89 (TreeSim resets its
  * arena, src/sims/tree.rs:363-365).  Host-side housekeeping that may overlap
  * the enqueued step.  No-op for the all-pairs simulator. */

@@ -28,7 +28,7 @@ class OracleSharded(ShardedStepper):
         posm[0][: self.n] = torch.from_numpy(state[:, [0, 1, 2, 9]])
         posm[1].copy_(posm[0])
 
-    def _local_step(self, src, dst):
+    def _step_remote(self, src, dst):
         full = np.zeros((self.n, 10), np.float32)
         full[:, [0, 1, 2, 9]] = src[: self.n].numpy()
         full[self.lo:self.hi, 3:9] = self.va[self.lo:self.hi]
@@ -46,6 +46,7 @@ def main():
     sim = OracleSharded(ShardPlan(n, world), rank, state)
     for _ in range(steps):
         sim.encode()
+    sim.finish_exchange()
     dist.barrier()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), posm=sim.posm[sim.cur][:n].numpy(),
              va=sim.va, lo=sim.lo, hi=sim.hi, step_num=sim.step_num)

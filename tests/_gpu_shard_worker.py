@@ -2,7 +2,7 @@
 2-process run of the PRODUCT sharded path (wgpu_n_body_amd.sharded.ShardedNaiveSim: HIP local
 step + in-place all-gather through torch.distributed) with both ranks on cuda:0 and the gloo
 backend standing in for RCCL (RCCL refuses two ranks on one device).
-argv: out_dir n steps [naive|tree]"""
+argv: out_dir n steps [naive|naive-overlap|tree]"""
 import os
 import sys
 
@@ -29,7 +29,7 @@ def main():
         sim = ShardedTreeSim(sp, 0.5, init, rank, world, 0)
         sim.lo, sim.hi = 0, n
     else:
-        sim = ShardedNaiveSim(sp, init, rank, world, 0, variant=1)
+        sim = ShardedNaiveSim(sp, init, rank, world, 0, variant=1, overlap=(mode == "naive-overlap"))
         sim.sim.set_tuning("naive_jsplit", 1)
     for _ in range(steps):
         sim.encode()

@@ -223,6 +223,10 @@ class Simulator:
     def encode(self) -> None:
         check(_lib.lib().nb_sim_encode(self._h))
 
+    def encode_phase(self, phase: int) -> None:
+        """Half a step (nb_sim_encode_phase): 0 = own bodies' tiles, 1 = the rest + integrate."""
+        check(_lib.lib().nb_sim_encode_phase(self._h, int(phase)))
+
     # -- Simulator::cleanup --
     def cleanup(self) -> None:
         check(_lib.lib().nb_sim_cleanup(self._h))

@@ -141,8 +141,12 @@ int NaiveSim::init(const nb_particle *host, size_t count) {
 
 // The j-split path needs room for its partial sums; (re)allocated whenever the plan changes.
 int NaiveSim::ensure_workspace() {
-    const NaivePlan p = plan_naive(n, hi - lo, variant, jsplit);
-    if (p.jsplit > 1 && p.jsplit > partial_slices) {
+    // room for whichever shape needs more slices: the single-launch or the two-phase step
+    const NaivePlan p1 = plan_naive(n, lo, hi, variant, jsplit, false);
+    const NaivePlan p2 = plan_naive(n, lo, hi, variant, jsplit, place.world > 1);
+    NaivePlan p = p1;
+    if (p2.two_phase && p2.jsplit > p.jsplit) p.jsplit = p2.jsplit;
+    if ((p.jsplit > 1 || p2.two_phase) && p.jsplit > partial_slices) {
         if (int rc = bind_device()) return rc;
         NB_HIP_TRY(hipStreamSynchronize(stream));
         if (partial) NB_HIP_TRY(hipFree(partial));
@@ -161,6 +165,7 @@ int NaiveSim::write_particles(const nb_particle *host, size_t count) {
     }
     if (int rc = bind_device()) return rc;
     if (n == 0) return NB_OK;
+    local_done = false;  // a first half enqueued for the old state is void
     NB_HIP_TRY(hipMemcpyAsync(d_aos, host, sizeof(nb_particle) * (size_t)n, hipMemcpyHostToDevice,
                               stream));
     NB_HIP_TRY(launch_aos_to_soa(d_aos, posm[cur], vel, acc, n, lo, hi, stream));
@@ -171,9 +176,7 @@ int NaiveSim::write_particles(const nb_particle *host, size_t count) {
     return NB_OK;
 }
 
-// NaiveSim::encode, src/sims/naive.rs:147-162: one dispatch, then flip the ping-pong.
-int NaiveSim::encode() {
-    if (int rc = bind_device()) return rc;
+int NaiveSim::launch(int phase) {
     NaiveLaunch a{};
     a.posm_src = posm[cur];
     a.posm_dst = posm[cur ^ 1];
@@ -191,7 +194,54 @@ int NaiveSim::encode() {
     a.partial = partial;
     a.partial_stride = per_rank;
     a.partial_slices = partial_slices;
+    a.phase = phase;
     NB_HIP_TRY(launch_naive_step(a, stream));
+    return NB_OK;
+}
+
+// NaiveSim::encode, src/sims/naive.rs:147-162: one dispatch, then flip the ping-pong.
+int NaiveSim::encode() {
+    if (int rc = bind_device()) return rc;
+    if (local_done) return encode_phase(1);  // the step's first half is already enqueued
+    if (int rc = launch(kPhaseAll)) return rc;
+    cur ^= 1;
+    step_num += 1;
+    return NB_OK;
+}
+
+// The step in two halves, for overlapping the multi-GPU exchange with compute:
+//   phase 0: partial sums over the rank's OWN j tiles.  They only need this rank's slice of the
+//            current positions, so the caller may enqueue phase 0 of step k+1 right after step
+//            k, while the all-gather of step k's other slices is still in flight;
+//   phase 1: partial sums over all other j tiles (after the all-gather), then the finish
+//            kernel (fixed-order sum + integrator) and the ping-pong flip.
+int NaiveSim::encode_phase(int phase) {
+    if (int rc = bind_device()) return rc;
+    const NaivePlan p = plan_naive(n, lo, hi, variant, jsplit, true);
+    if (!p.two_phase) {  // nothing to split (single rank, or a rank without bodies)
+        if (phase == 0) return NB_OK;
+        if (int rc = launch(kPhaseAll)) return rc;
+        cur ^= 1;
+        step_num += 1;
+        return NB_OK;
+    }
+    if (phase == 0) {
+        if (local_done) {
+            set_error("encode_phase(0) called twice for one step");
+            return NB_ERR_INVALID;
+        }
+        if (int rc = launch(kPhaseLocal)) return rc;
+        local_done = true;
+        return NB_OK;
+    }
+    if (phase != 1) {
+        set_error("encode_phase: phase must be 0 or 1");
+        return NB_ERR_INVALID;
+    }
+    if (!local_done)
+        if (int rc = launch(kPhaseLocal)) return rc;
+    if (int rc = launch(kPhaseRemote)) return rc;
+    local_done = false;
     cur ^= 1;
     step_num += 1;
     return NB_OK;
@@ -394,6 +444,7 @@ int nb_sim_create_from_particles(nb_sim **out, const nb_sim_params *sim_params,
     })
 
 int nb_sim_encode(nb_sim *sim) { NB_SIM_CALL(sim, encode()) }
+int nb_sim_encode_phase(nb_sim *sim, int phase) { NB_SIM_CALL(sim, encode_phase(phase)) }
 int nb_sim_cleanup(nb_sim *sim) { NB_SIM_CALL(sim, cleanup()) }
 int nb_sim_wait(nb_sim *sim) { NB_SIM_CALL(sim, wait()) }
 

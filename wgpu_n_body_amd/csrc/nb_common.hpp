@@ -50,14 +50,19 @@ struct NaiveLaunch {
     float4 *partial;         // [partial_slices][partial_stride] partial sums (j-split only)
     uint32_t partial_stride; // bodies per slice (>= hi-lo)
     uint32_t partial_slices; // slices allocated
+    int phase;               // kPhaseAll / kPhaseLocal / kPhaseRemote
 };
-// How a launch will be shaped for (n total bodies, n_local owned bodies).
+enum { kPhaseAll = 0, kPhaseLocal = 1, kPhaseRemote = 2 };
+// How a launch will be shaped for n total bodies of which this rank owns [lo, hi).
 struct NaivePlan {
     int variant;
-    uint32_t blocks;  // i-tiles
-    uint32_t jsplit;  // workgroups per i-tile (1 = single-kernel step)
+    uint32_t blocks;       // i-tiles
+    uint32_t jsplit;       // partial-sum slices per step (1 = single-kernel step)
+    uint32_t js_local, js_remote;          // two-phase: slices of the own / the other j tiles
+    uint32_t n_tiles, lo_tile, local_tiles;
+    bool two_phase;
 };
-NaivePlan plan_naive(uint32_t n, uint32_t n_local, int variant, int jsplit);
+NaivePlan plan_naive(uint32_t n, uint32_t lo, uint32_t hi, int variant, int jsplit, bool two_phase);
 hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream);
 int naive_variant_count();
 const char *naive_variant_name(int v);

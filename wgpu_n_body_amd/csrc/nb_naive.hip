@@ -35,6 +35,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum JSource { kLds = 0, kSmem = 1 };
 
+// Which j tiles a launch sums.  Virtual tile v in [0, count) maps to the real tile
+// base + v + (v >= skip_at ? skip_len : 0).  {0, n_tiles, ~0, 0} = all tiles.  A two-phase
+// (overlapped) step sums the rank's OWN tiles first ({lo_tile, local, ~0, 0}: their positions
+// are already on this GPU) and the others after the all-gather ({0, rest, lo_tile, local}).
+struct TileWindow {
+    uint32_t base, count, skip_at, skip_len;
+    __device__ __forceinline__ uint32_t tile(uint32_t v) const {
+        return base + v + (v >= skip_at ? skip_len : 0u);
+    }
+};
+
 // The O(N) integrator lines are evaluated exactly as naive.wgsl:63-66 writes them -- one
 // rounding per operation, no FMA contraction -- so a body's new position is bit-identical
 // to the literal fp32 oracle's (it depends only on the body's own x, v, a).
@@ -134,7 +145,7 @@ template <int IB, int W, int SRC, bool PACKED, int UNROLL>
 __global__ __launch_bounds__(64 * W) void naive_step_kernel(
     const float4 *__restrict__ posm_src, float4 *__restrict__ posm_dst, float4 *__restrict__ vel,
     float4 *__restrict__ acc, float4 *__restrict__ partial, uint32_t partial_stride, uint32_t n,
-    uint32_t n_pad, uint32_t lo, uint32_t hi, float g, float e, float dt) {
+    uint32_t n_pad, uint32_t lo, uint32_t hi, float g, float e, float dt, TileWindow win) {
     static_assert(!PACKED || IB % 2 == 0, "packed fp32 needs an even number of bodies per lane");
     using T = typename std::conditional<PACKED, v2f, float>::type;
     constexpr int NV = PACKED ? IB / 2 : IB;
@@ -177,14 +188,15 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
     const uint32_t t_self_lo = i0 / kJTile, t_self_hi = (i0 + 64u * IB - 1u) / kJTile;
     if constexpr (SRC == kLds) {
         float4 *my = s_tile + wave * 2 * kJTile;
-        uint32_t t = slot;
-        float4 nxt = t < n_tiles ? posm_src[t * kJTile + lane] : float4{0, 0, 0, 0};
+        uint32_t vt = slot;
+        float4 nxt = vt < win.count ? posm_src[win.tile(vt) * kJTile + lane] : float4{0, 0, 0, 0};
         uint32_t buf = 0;
-        for (; t < n_tiles; t += n_slots) {
+        for (; vt < win.count; vt += n_slots) {
+            const uint32_t t = win.tile(vt);
             my[buf * kJTile + lane] = nxt;  // ds_write_b128; wave-private, no s_barrier needed
             __builtin_amdgcn_wave_barrier();
-            const uint32_t tn = t + n_slots;
-            if (tn < n_tiles) nxt = posm_src[tn * kJTile + lane];  // prefetch the next tile
+            const uint32_t vn = vt + n_slots;
+            if (vn < win.count) nxt = posm_src[win.tile(vn) * kJTile + lane];  // prefetch next tile
             const float4 *tile = my + buf * kJTile;
             const bool special = (t >= t_self_lo && t <= t_self_hi) || (t + 1u == n_tiles);
             if (special)
@@ -196,7 +208,8 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
             buf ^= 1u;
         }
     } else {
-        for (uint32_t t = slot; t < n_tiles; t += n_slots) {
+        for (uint32_t vt = slot; vt < win.count; vt += n_slots) {
+            const uint32_t t = win.tile(vt);
             const float4 *tile = posm_src + t * kJTile;  // wave-uniform -> s_load_dwordx4+
             const bool special = (t >= t_self_lo && t <= t_self_hi) || (t + 1u == n_tiles);
             if (special)
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
         }
     }
 
-    if (gridDim.y > 1) {  // j-split: hand the partial sums to naive_finish_kernel
+    if (partial) {  // j-split / two-phase step: hand the partial sums to naive_finish_kernel
 #pragma unroll
         for (int k = 0; k < IB; ++k)
             if (ii[k] < hi)
@@ -322,7 +335,7 @@ __global__ void soa_to_aos_kernel(const float4 *__restrict__ posm, const float4 
 
 // ---- variant table ----------------------------------------------------------------------------
 using KernelFn = void (*)(const float4 *, float4 *, float4 *, float4 *, float4 *, uint32_t,
-                          uint32_t, uint32_t, uint32_t, uint32_t, float, float, float);
+                          uint32_t, uint32_t, uint32_t, uint32_t, float, float, float, TileWindow);
 struct Variant {
     const char *name;
     KernelFn fn;
@@ -369,38 +382,75 @@ const char *naive_variant_name(int v) {
     return (v >= 0 && v < kNumVariants) ? kVariants[v].name : "?";
 }
 
-NaivePlan plan_naive(uint32_t n, uint32_t n_local, int variant, int jsplit) {
+static uint32_t pick_jsplit(uint32_t blocks, uint32_t tiles, uint32_t waves, int forced) {
+    const uint32_t max_js = tiles / waves ? tiles / waves : 1u;  // >= 1 tile per wave
+    uint32_t js = 1;
+    if (forced > 0)
+        js = (uint32_t)forced;
+    else if (blocks && blocks < kTargetBlocks)
+        js = (kTargetBlocks + blocks - 1u) / blocks;
+    if (js > max_js) js = max_js;
+    if (js > kMaxJSplit) js = kMaxJSplit;
+    return js ? js : 1u;
+}
+
+NaivePlan plan_naive(uint32_t n, uint32_t lo, uint32_t hi, int variant, int jsplit, bool two_phase) {
     NaivePlan p{};
     p.variant = (variant >= 0 && variant < kNumVariants) ? variant : kAutoVariant;
     const Variant &v = kVariants[p.variant];
     const uint32_t itile = 64u * (uint32_t)v.ib;
+    const uint32_t n_local = hi > lo ? hi - lo : 0u;
     p.blocks = n_local ? (n_local + itile - 1u) / itile : 0u;
-    const uint32_t n_tiles = (n + kJTile - 1u) / kJTile;
-    const uint32_t max_js = n_tiles / (uint32_t)v.w ? n_tiles / (uint32_t)v.w : 1u;  // >= 1 tile per wave
-    uint32_t js = 1;
-    if (jsplit > 0)
-        js = (uint32_t)jsplit;
-    else if (p.blocks && p.blocks < kTargetBlocks)
-        js = (kTargetBlocks + p.blocks - 1u) / p.blocks;
-    if (js > max_js) js = max_js;
-    if (js > kMaxJSplit) js = kMaxJSplit;
-    p.jsplit = js ? js : 1u;
+    p.n_tiles = (n + kJTile - 1u) / kJTile;
+    p.lo_tile = lo / kJTile;
+    p.local_tiles = (n_local + kJTile - 1u) / kJTile;
+    p.two_phase = two_phase && n_local > 0 && p.local_tiles < p.n_tiles;
+    if (p.two_phase) {
+        p.js_local = pick_jsplit(p.blocks, p.local_tiles, (uint32_t)v.w, jsplit);
+        p.js_remote = pick_jsplit(p.blocks, p.n_tiles - p.local_tiles, (uint32_t)v.w, jsplit);
+        p.jsplit = p.js_local + p.js_remote;
+    } else {
+        p.jsplit = pick_jsplit(p.blocks, p.n_tiles, (uint32_t)v.w, jsplit);
+        p.js_local = 0;
+        p.js_remote = p.jsplit;
+    }
     return p;
 }
 
+// phase: kPhaseAll = the whole step; kPhaseLocal = partial sums over the rank's own j tiles only;
+// kPhaseRemote = partial sums over everybody else's tiles, then the finish kernel.
 hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream) {
     if (a.hi <= a.lo) return hipSuccess;  // a rank that owns no bodies
-    const NaivePlan p = plan_naive(a.n, a.hi - a.lo, a.variant, a.jsplit);
+    const NaivePlan p = plan_naive(a.n, a.lo, a.hi, a.variant, a.jsplit, a.phase != kPhaseAll);
     const Variant &v = kVariants[p.variant];
-    if (p.jsplit > 1 && (!a.partial || a.partial_slices < p.jsplit)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(v.fn, dim3(p.blocks, p.jsplit), dim3(64u * (uint32_t)v.w), 0, stream,
-                       a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride, a.n,
-                       a.n_pad, a.lo, a.hi, a.g, a.e, a.dt);
-    if (p.jsplit > 1) {
-        const uint32_t nl = a.hi - a.lo;
+    const dim3 block(64u * (uint32_t)v.w);
+    const uint32_t nl = a.hi - a.lo;
+    if (a.phase == kPhaseAll) {
+        if (p.jsplit > 1 && (!a.partial || a.partial_slices < p.jsplit)) return hipErrorInvalidValue;
+        const TileWindow all{0u, p.n_tiles, ~0u, 0u};
+        hipLaunchKernelGGL(v.fn, dim3(p.blocks, p.jsplit), block, 0, stream, a.posm_src, a.posm_dst,
+                           a.vel, a.acc, p.jsplit > 1 ? a.partial : (float4 *)nullptr, a.partial_stride,
+                           a.n, a.n_pad, a.lo, a.hi, a.g, a.e, a.dt, all);
+        if (p.jsplit > 1)
+            hipLaunchKernelGGL(naive_finish_kernel, dim3((nl + 255u) / 256u), dim3(256), 0, stream,
+                               a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride,
+                               p.jsplit, a.lo, a.hi, a.g, a.dt);
+        return hipGetLastError();
+    }
+    if (!p.two_phase || !a.partial || a.partial_slices < p.jsplit) return hipErrorInvalidValue;
+    if (a.phase == kPhaseLocal) {
+        const TileWindow own{p.lo_tile, p.local_tiles, ~0u, 0u};
+        hipLaunchKernelGGL(v.fn, dim3(p.blocks, p.js_local), block, 0, stream, a.posm_src, a.posm_dst,
+                           a.vel, a.acc, a.partial, a.partial_stride, a.n, a.n_pad, a.lo, a.hi, a.g,
+                           a.e, a.dt, own);
+    } else {
+        const TileWindow rest{0u, p.n_tiles - p.local_tiles, p.lo_tile, p.local_tiles};
+        hipLaunchKernelGGL(v.fn, dim3(p.blocks, p.js_remote), block, 0, stream, a.posm_src, a.posm_dst,
+                           a.vel, a.acc, a.partial + (size_t)p.js_local * a.partial_stride,
+                           a.partial_stride, a.n, a.n_pad, a.lo, a.hi, a.g, a.e, a.dt, rest);
         hipLaunchKernelGGL(naive_finish_kernel, dim3((nl + 255u) / 256u), dim3(256), 0, stream,
-                           a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride,
-                           p.jsplit, a.lo, a.hi, a.g, a.dt);
+                           a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride, p.jsplit,
+                           a.lo, a.hi, a.g, a.dt);
     }
     return hipGetLastError();
 }

@@ -19,6 +19,10 @@ class SimBase {
 
     virtual int init(const nb_particle *host, size_t count) = 0;          // Simulator::new
     virtual int encode() = 0;                                             // Simulator::encode
+    virtual int encode_phase(int) {
+        set_error("this simulator has no two-phase step");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int cleanup() { return NB_OK; }                               // Simulator::cleanup
     virtual int read_particles(nb_particle *dst, size_t count) = 0;       // dest_particle_slice
     virtual int write_particles(const nb_particle *src, size_t count) = 0;
@@ -55,6 +59,7 @@ class NaiveSim final : public SimBase {
     ~NaiveSim() override;
     int init(const nb_particle *host, size_t count) override;
     int encode() override;
+    int encode_phase(int phase) override;
     int read_particles(nb_particle *dst, size_t count) override;
     int write_particles(const nb_particle *src, size_t count) override;
     int encode_n_timed(int count, float *ms_total, float *ms_kernel) override;
@@ -72,6 +77,8 @@ class NaiveSim final : public SimBase {
     float4 *partial = nullptr;              // j-split partial sums [slices][per_rank]
     uint32_t partial_slices = 0;
     int ensure_workspace();
+    int launch(int phase);
+    bool local_done = false;                // phase 0 of the NEXT step already enqueued
     std::vector<hipEvent_t> events;
 };
 

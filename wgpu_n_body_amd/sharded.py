@@ -46,12 +46,19 @@ class ShardPlan:
 
 
 class ShardedStepper:
-    """Host logic of the sharded step, independent of where the local step runs.
+    """Host logic of the sharded step, independent of where the local work runs.
 
-    Subclasses provide `_local_step(src, dst)`: advance this rank's bodies reading the full
-    `src` position buffer and writing rows [lo, hi) of `dst`.  `posm` are two torch tensors
+    One step of rank r:   [own-tiles half]  ->  wait for the previous exchange  ->
+                          [other-tiles half + integrate]  ->  start the exchange (async)  ->
+                          [own-tiles half of the NEXT step, overlapping the exchange]
+    The own-tiles half only reads this rank's slice of the position buffer, which the rank
+    itself wrote, so it is safe while the in-place all-gather is still filling the other
+    slices.  Subclasses provide `_step_local(src)` (may be a no-op) and `_step_remote(src, dst)`
+    (everything else; must leave rows [lo, hi) of `dst` final).  `posm` are two torch tensors
     of shape [padded, 4] that ping-pong, exactly like the reference's two particle buffers.
     """
+
+    overlap = True
 
     def __init__(self, plan: ShardPlan, rank: int, posm, group=None):
         self.plan, self.rank, self.group = plan, rank, group
@@ -59,43 +66,64 @@ class ShardedStepper:
         self.cur = 0          # posm[cur] holds the current positions of ALL bodies
         self.step_num = 0
         self.lo, self.hi = plan.range(rank)
+        self._work = None            # the exchange in flight, if any
+        self._local_issued = False   # own-tiles half of the next step already enqueued
 
-    def _local_step(self, src, dst) -> None:  # pragma: no cover - abstract
+    def _step_local(self, src) -> None:
+        pass
+
+    def _step_remote(self, src, dst) -> None:  # pragma: no cover - abstract
         raise NotImplementedError
 
-    def exchange(self, buf) -> None:
+    def start_exchange(self, buf) -> None:
         """In-place all-gather: every rank contributes rows [rank*per, (rank+1)*per)."""
         import torch.distributed as dist
         if self.plan.world == 1:
             return
         per = self.plan.per_rank
         mine = buf[self.rank * per:(self.rank + 1) * per]
-        dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self.group)
+        self._work = dist.all_gather_into_tensor(buf.view(-1), mine.reshape(-1), group=self.group,
+                                                 async_op=True)
+
+    def finish_exchange(self) -> None:
+        """Order everything enqueued from now on after the exchange in flight."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
 
     def encode(self, events=None) -> None:
         """One sharded step.  `events`: optional (start, end) timing events recorded around
-        the local step only (bench.py's kernel-duration measurement)."""
+        the post-exchange half of the step."""
         src, dst = self.posm[self.cur], self.posm[self.cur ^ 1]
+        if not self._local_issued:
+            self._step_local(src)
+        self.finish_exchange()                 # src is complete from here on
         if events:
             events[0].record()
-        self._local_step(src, dst)
+        self._step_remote(src, dst)
         if events:
             events[1].record()
-        self.exchange(dst)
+        self._local_issued = False
+        self.start_exchange(dst)
         self.cur ^= 1
         self.step_num += 1
+        if self.overlap and self.plan.world > 1:
+            self._step_local(dst)              # next step's first half, beside the all-gather
+            self._local_issued = True
 
 
 class ShardedNaiveSim(ShardedStepper):
-    """The product path: nb_naive.hip for the local step, RCCL for the exchange."""
+    """The product path: nb_naive.hip for the local work, RCCL for the exchange."""
 
     def __init__(self, sim_params: SimParams, particles, rank: int, world: int,
-                 device_index: int, group=None, variant: Optional[int] = None):
+                 device_index: int, group=None, variant: Optional[int] = None,
+                 overlap: bool = True):
         import torch
         plan = ShardPlan(sim_params.particle_num, world)
         dev = torch.device("cuda", device_index)
         posm = [torch.zeros(plan.padded, 4, dtype=torch.float32, device=dev) for _ in range(2)]
         super().__init__(plan, rank, posm, group)
+        self.overlap = overlap
         self._torch = torch
         self._dev = dev
         # A dedicated (non-null) stream: the kernels and the collective's stream dependencies
@@ -113,10 +141,15 @@ class ShardedNaiveSim(ShardedStepper):
         ptr = self.sim.exchange_region()[0]
         self.cur = 0 if ptr == posm[0].data_ptr() else 1
 
-    def _local_step(self, src, dst) -> None:
-        self.sim.encode()            # async, on self.stream
-        ptr = self.sim.exchange_region()[0]
-        assert ptr == dst.data_ptr(), "ping-pong out of sync with the simulator"
+    def _step_local(self, src) -> None:
+        if self.overlap:
+            self.sim.encode_phase(0)     # async, on self.stream: the rank's own j tiles
+
+    def _step_remote(self, src, dst) -> None:
+        if self.overlap:
+            self.sim.encode_phase(1)     # the other j tiles, the integrator, the ping-pong flip
+        else:
+            self.sim.encode()            # the whole step in one go (no overlap with the exchange)
 
     def encode(self, events=None) -> None:
         with self._torch.cuda.stream(self.stream):   # the collective orders against it
@@ -126,14 +159,18 @@ class ShardedNaiveSim(ShardedStepper):
         self.sim.cleanup()
 
     def wait(self) -> None:
+        with self._torch.cuda.stream(self.stream):
+            self.finish_exchange()
         self.stream.synchronize()
 
     def read_particles(self) -> np.ndarray:
         """All positions/masses + this rank's velocities/accelerations (zero elsewhere)."""
+        self.wait()
         self._torch.cuda.synchronize(self._dev)
         return self.sim.dest_particle_slice()
 
     def destroy(self) -> None:
+        self.wait()
         self.sim.destroy()
 
 
