@@ -50,7 +50,10 @@ constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
 constexpr uint32_t kIdThreads = 256;
-constexpr uint32_t kWalkStack = 384;   // wave-level stack entries (16 B each)
+constexpr uint32_t kWalkStack = 320;   // wave-level stack entries (16 B each): 5 KiB per wave
+// batch-pop only while sp <= this: 4 x 7 net pushes + 7 per level of a depth-first descent
+// over 21 levels still fit (140 + 28 + 147 <= 320), so the stack cannot overflow
+constexpr uint32_t kWalkBatchMaxSp = 140;
 
 __device__ __forceinline__ float kick(float v, float a, float dt) {
 #pragma clang fp contract(off)
@@ -64,14 +67,20 @@ __device__ __forceinline__ float drift(float x, float v, float dt) {
 // ---- 1. bound -----------------------------------------------------------------------------------
 // max over bodies and axes of |coord|, never below 1.0 (rayon reduce identity [1.0;3],
 // tree.rs:427-433).  Non-negative floats order like their bit patterns -> atomicMax on u32.
-__global__ void bound_kernel(const float4 *__restrict__ posm, uint32_t n, uint32_t *bound_bits) {
+__global__ __launch_bounds__(256) void bound_kernel(const float4 *__restrict__ posm, uint32_t n,
+                                                    uint32_t *bound_bits) {
+    __shared__ float s_m[4];
     float m = 1.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = posm[i];
         m = fmaxf(m, fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))));
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(bound_bits, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup: thousands of atomics on one word serialise (~12 ns each)
+    if (threadIdx.x == 0)
+        atomicMax(bound_bits, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
 // ---- 2. keys ------------------------------------------------------------------------------------
@@ -482,6 +491,22 @@ __global__ void level_mass_kernel(const uint32_t *__restrict__ depth_base, int d
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
+// What the walk reads per cell, in one 32-byte scalar load: centre of gravity + mass, and the
+// link {first child id, child count} (leaf: {sorted position of its body, 0}).
+struct __attribute__((aligned(32))) NodeRec {
+    float4 cogm;
+    uint32_t first, count, pad0, pad1;
+};
+
+__global__ void pack_nodes_kernel(const float4 *__restrict__ cogm, const uint2 *__restrict__ link,
+                                  const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
+                                  NodeRec *__restrict__ rec) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= min(*n_nodes_p, n_cap)) return;
+    const uint2 lk = link[id];
+    rec[id] = NodeRec{cogm[id], lk.x, lk.y, 0u, 0u};
+}
+
 // Stack entry: cell id (27 bits) | depth << 27, and the 64-bit mask of lanes that visit it.
 struct StackEntry {
     uint32_t node_depth;
@@ -495,25 +520,21 @@ constexpr uint32_t kNodeBits = 27;  // 2^27 cells: 4N nodes for up to 33 M bodie
 // Acceptance test size/dist < theta (tree.wgsl:63-64) in squared form, size^2 < theta^2 r^2:
 // no sqrt or reciprocal unless some lane accumulates the cell.
 template <bool COUNT>
-__device__ __forceinline__ uint64_t visit_cell(const float4 q, const uint2 lk, uint32_t depth,
-                                               bool mine, uint32_t my_pos, float xi, float yi,
-                                               float zi, float root_width, float theta2, float e,
-                                               float &ax, float &ay, float &az,
+__device__ __forceinline__ uint64_t visit_cell(const float4 q, uint32_t first, uint32_t count,
+                                               uint32_t depth, bool mine, uint32_t my_pos, float xi,
+                                               float yi, float zi, float root_width, float theta2,
+                                               float e, float &ax, float &ay, float &az,
                                                unsigned long long &visits,
                                                unsigned long long &accepts) {
     // size_stack: root_width halved `depth` times (exact: a power-of-two scaling, tree.wgsl:82)
     const float size = root_width * __uint_as_float((127u - depth) << 23);
     const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    bool take;
-    uint64_t open = 0;
-    if (lk.y == 0u) {  // a leaf is a body: always accumulate, except the body itself
-        take = mine && lk.x != my_pos;
-    } else {
-        const bool far = size * size < theta2 * r2;
-        take = mine && far;
-        open = __ballot(mine && !far);
-    }
+    const bool leaf = count == 0u;  // wave-uniform
+    // a leaf is a body: always taken, except the body itself; a cell is taken when far enough
+    const bool far = leaf ? first != my_pos : size * size < theta2 * r2;
+    const bool take = mine && far;
+    const uint64_t open = leaf ? 0ull : __ballot(mine && !far);
     if (take) {
         const float dist = __builtin_amdgcn_sqrtf(r2);
         const float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
@@ -531,8 +552,8 @@ __device__ __forceinline__ uint64_t visit_cell(const float4 q, const uint2 lk, u
 template <bool COUNT>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
-    const float4 *__restrict__ acc_src, const float4 *__restrict__ cogm,
-    const uint2 *__restrict__ link, const uint32_t *__restrict__ bound_bits,
+    const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
+    const uint32_t *__restrict__ bound_bits,
     const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, float4 *__restrict__ posm_dst,
     float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst, uint32_t n, uint32_t lo, uint32_t hi,
     float g, float e, float dt, float theta, uint32_t *__restrict__ status,
@@ -553,6 +574,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float theta2 = theta * theta;
     const uint32_t lane_lo = lane < 32u ? 1u << lane : 0u, lane_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
     unsigned long long visits = 0, accepts = 0;
+    uint32_t wave_cells = 0, max_sp = 1;
 
     StackEntry *stack = s_stack[wave];
     uint32_t sp = 0;
@@ -567,16 +589,18 @@ __global__ __launch_bounds__(256) void walk_kernel(
     while (sp > 0) {
         // pop up to kWalkBatch cells and fetch them together: their (wave-uniform, scalar)
         // loads overlap instead of forming one dependent chain per cell
-        const uint32_t nb = sp < kWalkBatch ? sp : kWalkBatch;
+        // (only while the stack has room for 4 x 8 children plus a pure depth-first descent
+        // below them; beyond that pop one cell at a time, which bounds growth by 7 per level)
+        const uint32_t nb = sp > kWalkBatchMaxSp ? 1u : (sp < kWalkBatch ? sp : kWalkBatch);
         if (budget <= nb) {
             if (lane == 0) atomicAdd(&status[3], 1u);
             break;
         }
         budget -= nb;
         sp -= nb;
+        if (COUNT) wave_cells += nb;
         uint32_t e_node[kWalkBatch], e_depth[kWalkBatch], e_lo[kWalkBatch], e_hi[kWalkBatch];
-        float4 q[kWalkBatch];
-        uint2 lk[kWalkBatch];
+        NodeRec r[kWalkBatch];
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
             const StackEntry t = stack[sp + (b < nb ? nb - 1u - b : 0u)];  // b = 0 is the old top
@@ -588,19 +612,17 @@ __global__ __launch_bounds__(256) void walk_kernel(
             e_hi[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask_hi);
         }
 #pragma unroll
-        for (uint32_t b = 0; b < kWalkBatch; ++b) {
-            q[b] = cogm[e_node[b]];
-            lk[b] = link[e_node[b]];
-        }
+        for (uint32_t b = 0; b < kWalkBatch; ++b) r[b] = rec[e_node[b]];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
             if (b >= nb) break;
             const bool mine = ((e_lo[b] & lane_lo) | (e_hi[b] & lane_hi)) != 0u;
-            const uint64_t open = visit_cell<COUNT>(q[b], lk[b], e_depth[b], mine, i, xi, yi, zi,
-                                                    root_width, theta2, e, ax, ay, az, visits, accepts);
+            const uint64_t open = visit_cell<COUNT>(r[b].cogm, r[b].first, r[b].count, e_depth[b], mine,
+                                                    i, xi, yi, zi, root_width, theta2, e, ax, ay, az,
+                                                    visits, accepts);
             if (open) {  // push the children (contiguous ids, octant order) for the opening lanes
-                const uint32_t cnt = lk[b].y, first = lk[b].x;
+                const uint32_t cnt = r[b].count, first = r[b].first;
                 if (sp + cnt > kWalkStack || first + cnt > n_nodes) {
                     if (lane == 0) atomicAdd(&status[0], 1u);
                 } else {
@@ -608,10 +630,15 @@ __global__ __launch_bounds__(256) void walk_kernel(
                         stack[sp + lane] = StackEntry{(first + lane) | ((e_depth[b] + 1u) << kNodeBits),
                                                       (uint32_t)open, (uint32_t)(open >> 32), 0u};
                     sp += cnt;
+                    if (COUNT) max_sp = sp > max_sp ? sp : max_sp;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (COUNT && lane == 0) {  // per-wave statistics: cells fetched, deepest stack
+        atomicAdd(&counters[2], (unsigned long long)wave_cells);
+        atomicMax(&counters[3], (unsigned long long)max_sp);
     }
     if (!valid) return;
     const float gdt = g * dt;
@@ -702,6 +729,7 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&node_depth, (size_t)node_cap)) return rc;
         if (int rc = alloc(&cogm, sizeof(float4) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&link, sizeof(uint2) * (size_t)node_cap)) return rc;
+        if (int rc = alloc(&rec, sizeof(NodeRec) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&bodies, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
         if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
@@ -742,7 +770,7 @@ class TreeSim final : public SimBase {
         const uint32_t g256 = (n + 255) / 256;
         // 1-2: bound + keys from the step's source positions (old positions, tree.rs:290-295)
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));  // status words are sticky
-        hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 1024)), b256, 0, stream, posm[s], n,
+        hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
                            bound_bits);
         hipLaunchKernelGGL(morton_kernel, dim3(g256), b256, 0, stream, posm[s], n, bound_bits, keys[0],
                            idx[0]);
@@ -785,17 +813,18 @@ class TreeSim final : public SimBase {
         for (int depth = kLevels; depth >= 0; --depth)
             hipLaunchKernelGGL(level_mass_kernel, dim3(level_blocks(depth)), b256, 0, stream, depth_base,
                                depth, node_cap, bodies, child, cogm);
+        hipLaunchKernelGGL(pack_nodes_kernel, dim3(gnodes), b256, 0, stream, cogm, link, n_nodes, node_cap, rec);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
             const dim3 gwalk((hi - lo + 255) / 256);
             if (count_visits)
-                hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], cogm,
-                                   link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
+                                   bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
             else
-                hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], cogm,
-                                   link, bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
+                                   bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
@@ -969,6 +998,7 @@ class TreeSim final : public SimBase {
     int8_t *cpl = nullptr;
     float4 *cogm = nullptr;
     uint2 *link = nullptr;  // per node {first child id, child count} / leaf {sorted position, 0}
+    NodeRec *rec = nullptr; // cogm + link packed for the walk
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false;
