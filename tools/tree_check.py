@@ -33,6 +33,10 @@ if not np.array_equal(tree["children"][:m], ref["tree"]["children"][:m]):
     for b in bad[:3]: print(b, tree[b], ref["tree"][b])
 print("mass rel err", np.abs(tree["mass"][:m] - ref["tree"]["mass"][:m]).max() / ref["tree"]["mass"][:m].max(),
       "cog abs err", np.abs(tree["cog"][:m] - ref["tree"]["cog"][:m]).max())
+merr = np.abs(tree["mass"][:m] - ref["tree"]["mass"][:m])
+worst = np.argsort(-merr)[:6]
+for w in worst:
+    print("  node", w, "bodies", tree["bodies"][w], "mass gpu", tree["mass"][w], "ref", ref["tree"]["mass"][w], "cog", tree["cog"][w], ref["tree"]["cog"][w])
 print("pos bit-equal:", np.array_equal(out[:, 0:3].view(np.uint32), ref["dst"][:, 0:3].view(np.uint32)))
 a, b = out[:, 6:9].astype(np.float64), ref["dst"][:, 6:9].astype(np.float64)
 rel = np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1)

@@ -22,8 +22,8 @@
 //                         allocation order (tree.rs:461,517-519; slice_alloc.rs:52-59).
 //   6 fill_kernel         per node: body range by binary search on the keys, children table
 //                         (0 = none; a leaf's children[0] = the body's source index, tree.rs:532)
-//   7 level_mass_kernel   bottom-up, one launch per depth: mass = sum of children,
-//                         cog = sum(m_c cog_c)/mass                             tree.rs:486-505
+//   7 moments_kernel      mass / centre of gravity of every cell from binary64 prefix sums of
+//                         (m x, m y, m z, m) over the sorted bodies             tree.rs:486-505
 //   8 walk_kernel         tree.wgsl:41-111 with the INTENDED semantics: self
 //                         excluded by identity, a leaf is a body, no fixed 64-entry stack.
 //                         One wave walks for 64 consecutive (spatially coherent) bodies with a
@@ -35,7 +35,7 @@
 //
 // Deviations, all documented in DESIGN.md: bodies whose 63-bit keys collide (closer than
 // root_width/2^21) cannot be separated (the reference would recurse until its 4N-node buffer
-// overflows); cog/mass are summed hierarchically instead of sequentially per cell.
+// overflows); cog/mass come from binary64 prefix sums instead of a sequential fp32 sum per cell.
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -399,12 +399,105 @@ __global__ __launch_bounds__(kIdThreads) void assign_ids_kernel(
         if (d == leafd) {
             leaf_id[k] = id;
         } else {
-            int_id[int_slot[k] + (uint32_t)(d - left - 1)] = id;
+            // (a clustered input can open far more internal cells than the 4N capacity)
+            const uint32_t slot = int_slot[k] + (uint32_t)(d - left - 1);
+            if (slot < cap) int_id[slot] = id;
         }
         if (id < cap) {
             node_first[id] = k;
             node_depth[id] = (uint8_t)(d | (d == leafd ? 0x80 : 0));
         }
+    }
+}
+
+// What the walk reads per cell, in one 32-byte scalar load: centre of gravity + mass, and the
+// link {first child id, child count} (leaf: {sorted position of its body, 0}).
+struct __attribute__((aligned(32))) NodeRec {
+    float4 cogm;
+    uint32_t first, count, pad0, pad1;
+};
+
+// ---- 6a. mass moments by prefix sums ------------------------------------------------------------
+// A cell's bodies are a contiguous run [k, end) of the sorted order, so its mass and centre of
+// gravity follow from exclusive prefix sums of (m x, m y, m z, m) over the sorted bodies:
+// sum = P[end] - P[k].  The sums are kept in binary64 -- a difference of fp32 prefix sums would
+// lose the small cells at the far end of the array (N eps relative error); in binary64 the
+// result is the correctly rounded moment to ~1e-10, where the reference's own sequential fp32
+// sum (tree.rs:486-505) is only good to ~1e-6.
+struct Moments {
+    double x, y, z, m;
+};
+__device__ __forceinline__ Moments operator+(const Moments &a, const Moments &b) {
+    return Moments{a.x + b.x, a.y + b.y, a.z + b.z, a.m + b.m};
+}
+constexpr uint32_t kMomTile = 1024;  // bodies per block (256 threads x 4)
+
+__device__ __forceinline__ Moments block_scan_moments(Moments v, Moments *s_wave, Moments *total) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Moments x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        Moments y{__shfl_up(x.x, o), __shfl_up(x.y, o), __shfl_up(x.z, o), __shfl_up(x.m, o)};
+        if ((int)lane >= o) x = x + y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    Moments off{0, 0, 0, 0};
+    for (uint32_t w = 0; w < wave; ++w) off = off + s_wave[w];
+    if (total) *total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    return Moments{off.x + x.x - v.x, off.y + x.y - v.y, off.z + x.z - v.z, off.m + x.m - v.m};
+}
+
+// pass 1 (sums != nullptr): per-block totals.  pass 2: prefix[k] for every body and prefix[n].
+__global__ __launch_bounds__(256) void moments_kernel(const float4 *__restrict__ posm, uint32_t n,
+                                                      Moments *__restrict__ block_sums,
+                                                      const Moments *__restrict__ block_offsets,
+                                                      Moments *__restrict__ prefix) {
+    __shared__ Moments s_wave[4];
+    Moments item[4], v{0, 0, 0, 0};
+    const uint32_t base = blockIdx.x * kMomTile + threadIdx.x * 4;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (base + j < n) {
+            const float4 p = posm[base + j];
+            const double m = (double)p.w;
+            item[j] = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
+        } else {
+            item[j] = Moments{0, 0, 0, 0};
+        }
+        v = v + item[j];
+    }
+    Moments total;
+    Moments run = block_scan_moments(v, s_wave, &total);
+    if (!prefix) {
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+        return;
+    }
+    run = run + block_offsets[blockIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (base + j <= n) prefix[base + j] = run;  // includes prefix[n] = grand total
+        run = run + item[j];
+    }
+}
+
+// exclusive scan of the (<= 4096) block totals, one workgroup
+__global__ __launch_bounds__(256) void moments_scan_kernel(const Moments *__restrict__ sums,
+                                                           uint32_t nblocks,
+                                                           Moments *__restrict__ offsets) {
+    __shared__ Moments s_wave[4];
+    __shared__ Moments s_carry;
+    if (threadIdx.x == 0) s_carry = Moments{0, 0, 0, 0};
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const Moments v = i < nblocks ? sums[i] : Moments{0, 0, 0, 0};
+        Moments total;
+        const Moments ex = block_scan_moments(v, s_wave, &total);
+        if (i < nblocks) offsets[i] = ex + s_carry;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = s_carry + total;
+        __syncthreads();
     }
 }
 
@@ -425,8 +518,9 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ int_slot,
                             const uint32_t *__restrict__ leaf_id, const uint32_t *__restrict__ int_id,
                             const uint32_t *__restrict__ order, const float4 *__restrict__ posm,
-                            float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
-                            uint32_t *__restrict__ child, uint2 *__restrict__ link) {
+                            const Moments *__restrict__ mom, float4 *__restrict__ cogm,
+                            uint32_t *__restrict__ bodies, uint32_t *__restrict__ child,
+                            NodeRec *__restrict__ rec) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     if (id >= n_nodes) return;
@@ -434,10 +528,11 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     const uint32_t dd = node_depth[id];
     uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
-        cogm[id] = posm[k];
+        const float4 p = posm[k];
+        cogm[id] = p;
         bodies[id] = 1;
         ch[0] = order[k];  // tree.rs:532
-        link[id] = uint2{k, 0u};  // walk: a leaf knows its body's sorted position
+        rec[id] = NodeRec{p, k, 0u, 0u, 0u};  // walk: a leaf knows its body's sorted position
     } else {
         const uint32_t d = dd;
         const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
@@ -453,60 +548,30 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                 if (e - b == 1) {
                     ch[c] = leaf_id[b];
                 } else {  // internal cell of depth d+1 opened by body b
-                    ch[c] = int_id[int_slot[b] + (d + 1u - (uint32_t)((int)cpl[b] + 1))];
+                    const uint32_t slot = int_slot[b] + (d + 1u - (uint32_t)((int)cpl[b] + 1));
+                    ch[c] = slot < n_cap ? int_id[slot] : 0u;
                 }
             }
             b = e;
         }
-        cogm[id] = float4{0.f, 0.f, 0.f, 0.f};
+        // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
+        const Moments a = mom[k], b2 = mom[end];
+        const double m = b2.m - a.m;
+        const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
+                                (float)((b2.z - a.z) / m), (float)m};
+        cogm[id] = q;
         // children are allocated contiguously in octant order (tree.rs:517-519), so the walk
         // only needs the first child's id and how many there are
         uint32_t first = 0, cnt = 0;
         for (int c = 7; c >= 0; --c)
             if (ch[c]) { first = ch[c]; ++cnt; }
-        link[id] = uint2{first, cnt};
+        rec[id] = NodeRec{q, first, cnt, 0u, 0u};
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
 }
 
-// ---- 7. bottom-up mass / centre of gravity, one depth per launch -------------------------------
-__global__ void level_mass_kernel(const uint32_t *__restrict__ depth_base, int depth, uint32_t n_cap,
-                                  const uint32_t *__restrict__ bodies,
-                                  const uint32_t *__restrict__ child, float4 *__restrict__ cogm) {
-    const uint32_t lo = depth_base[depth], hi = min(depth_base[depth + 1], n_cap);
-    const uint32_t id = lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= hi || bodies[id] == 1) return;
-    float sx = 0.f, sy = 0.f, sz = 0.f, m = 0.f;
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t ci = child[(size_t)id * 8 + c];
-        if (ci == 0 || ci >= n_cap) continue;
-        const float4 q = cogm[ci];
-        sx += q.x * q.w;
-        sy += q.y * q.w;
-        sz += q.z * q.w;
-        m += q.w;
-    }
-    cogm[id] = float4{sx / m, sy / m, sz / m, m};  // tree.rs:503-505
-}
-
 // ---- 8. walk + integrate ------------------------------------------------------------------------
-// What the walk reads per cell, in one 32-byte scalar load: centre of gravity + mass, and the
-// link {first child id, child count} (leaf: {sorted position of its body, 0}).
-struct __attribute__((aligned(32))) NodeRec {
-    float4 cogm;
-    uint32_t first, count, pad0, pad1;
-};
-
-__global__ void pack_nodes_kernel(const float4 *__restrict__ cogm, const uint2 *__restrict__ link,
-                                  const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
-                                  NodeRec *__restrict__ rec) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= min(*n_nodes_p, n_cap)) return;
-    const uint2 lk = link[id];
-    rec[id] = NodeRec{cogm[id], lk.x, lk.y, 0u, 0u};
-}
-
 // Stack entry: cell id (27 bits) | depth << 27, and the 64-bit mask of lanes that visit it.
 struct StackEntry {
     uint32_t node_depth;
@@ -685,6 +750,7 @@ class TreeSim final : public SimBase {
    public:
     ~TreeSim() override {
         (void)hipSetDevice(place.device_id);
+        drop_graph();
         for (void *p : allocs) (void)hipFree(p);
         for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
     }
@@ -728,8 +794,11 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&node_first, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_depth, (size_t)node_cap)) return rc;
         if (int rc = alloc(&cogm, sizeof(float4) * (size_t)node_cap)) return rc;
-        if (int rc = alloc(&link, sizeof(uint2) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&rec, sizeof(NodeRec) * (size_t)node_cap)) return rc;
+        mom_blocks = (uint32_t)((nn + 1 + kMomTile - 1) / kMomTile);  // covers prefix[n] too
+        if (int rc = alloc(&mom_sums, sizeof(Moments) * (size_t)mom_blocks)) return rc;
+        if (int rc = alloc(&mom_offsets, sizeof(Moments) * (size_t)mom_blocks)) return rc;
+        if (int rc = alloc(&mom_prefix, sizeof(Moments) * (nn + 1))) return rc;
         if (int rc = alloc(&bodies, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
         if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
@@ -756,12 +825,47 @@ class TreeSim final : public SimBase {
     }
 
     // TreeSim::encode, tree.rs:262-353 -- everything on the device, nothing mapped to the host.
+    // One step = ~60 small launches; they never change (same buffers, same arguments every
+    // step: the state lands back in buffer `cur`), so the sequence is captured into a hipGraph
+    // the first time and replayed afterwards -- one submission instead of sixty.
     int encode() override {
         if (int rc = bind_device()) return rc;
         if (n == 0) {
             step_num += 1;
             return NB_OK;
         }
+        if (!use_graph || time_walk) {
+            if (int rc = enqueue_step()) return rc;
+            step_num += 1;
+            return NB_OK;
+        }
+        if (!graph_exec) {
+            hipGraph_t graph = nullptr;
+            NB_HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_step();
+            const hipError_t ec = hipStreamEndCapture(stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            NB_HIP_TRY(ec);
+            const hipError_t ei = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            NB_HIP_TRY(ei);
+        }
+        NB_HIP_TRY(hipGraphLaunch(graph_exec, stream));
+        step_num += 1;
+        return NB_OK;
+    }
+
+    void drop_graph() {
+        if (graph_exec) {
+            (void)hipGraphExecDestroy(graph_exec);
+            graph_exec = nullptr;
+        }
+    }
+
+    int enqueue_step() {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
         uint32_t *zero_word = scalars + 8;    // stays 0
@@ -805,15 +909,16 @@ class TreeSim final : public SimBase {
         hipLaunchKernelGGL(assign_ids_kernel, dim3(id_blocks), dim3(kIdThreads), 0, stream, cpl, n, hist,
                            id_blocks, depth_base, int_slot, leaf_id, int_id, node_first, node_depth,
                            node_cap);
-        // 6-7: node contents, then mass/cog bottom-up
+        // 6: mass moments by binary64 prefix sums over the sorted bodies, then node contents
+        hipLaunchKernelGGL(moments_kernel, dim3(mom_blocks), b256, 0, stream, posm[d], n, mom_sums,
+                           (const Moments *)nullptr, (Moments *)nullptr);
+        hipLaunchKernelGGL(moments_scan_kernel, dim3(1), b256, 0, stream, mom_sums, mom_blocks, mom_offsets);
+        hipLaunchKernelGGL(moments_kernel, dim3(mom_blocks), b256, 0, stream, posm[d], n,
+                           (Moments *)nullptr, mom_offsets, mom_prefix);
         const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
-                           node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d], cogm,
-                           bodies, child, link);
-        for (int depth = kLevels; depth >= 0; --depth)
-            hipLaunchKernelGGL(level_mass_kernel, dim3(level_blocks(depth)), b256, 0, stream, depth_base,
-                               depth, node_cap, bodies, child, cogm);
-        hipLaunchKernelGGL(pack_nodes_kernel, dim3(gnodes), b256, 0, stream, cogm, link, n_nodes, node_cap, rec);
+                           node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
+                           mom_prefix, cogm, bodies, child, rec);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
@@ -830,14 +935,7 @@ class TreeSim final : public SimBase {
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
         NB_HIP_TRY(hipGetLastError());
         // the post-step state is in buffer s (= cur); buffer d holds the sorted source
-        step_num += 1;
         return NB_OK;
-    }
-
-    // nodes of depth `depth` are bounded by 8^depth and by the node capacity
-    uint32_t level_blocks(int depth) const {
-        const uint64_t bound = depth >= 11 ? (uint64_t)node_cap : std::min<uint64_t>(node_cap, 1ull << (3 * depth));
-        return (uint32_t)((bound + 255) / 256);
     }
 
     int read_particles(nb_particle *dst, size_t count) override {
@@ -949,6 +1047,12 @@ class TreeSim final : public SimBase {
     int set_tuning(const char *key, int value) override {
         if (std::strcmp(key, "tree_count_visits") == 0) {
             count_visits = value != 0;
+            drop_graph();  // a different walk kernel: re-capture
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_use_graph") == 0) {
+            use_graph = value != 0;
+            drop_graph();
             return NB_OK;
         }
         return SimBase::set_tuning(key, value);
@@ -997,11 +1101,13 @@ class TreeSim final : public SimBase {
     uint8_t *node_depth = nullptr;
     int8_t *cpl = nullptr;
     float4 *cogm = nullptr;
-    uint2 *link = nullptr;  // per node {first child id, child count} / leaf {sorted position, 0}
-    NodeRec *rec = nullptr; // cogm + link packed for the walk
+    NodeRec *rec = nullptr;  // per node: cogm + {first child id, child count} / leaf {sorted position, 0}
+    Moments *mom_sums = nullptr, *mom_offsets = nullptr, *mom_prefix = nullptr;
+    uint32_t mom_blocks = 0;
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
-    bool count_visits = false;
+    bool count_visits = false, use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
