@@ -414,7 +414,9 @@ __global__ __launch_bounds__(kIdThreads) void assign_ids_kernel(
 // link {first child id, child count} (leaf: {sorted position of its body, 0}).
 struct __attribute__((aligned(32))) NodeRec {
     float4 cogm;
-    uint32_t first, count, pad0, pad1;
+    uint32_t first, count;  // children ids first .. first+count-1 (octant order); leaf: count 0
+    uint32_t self_pos;      // leaf: sorted position of its body; cell: ~0 (matches no body)
+    float size_sign;        // cell: +1; leaf: -1, which makes "size^2 < theta^2 r^2" always true
 };
 
 // ---- 6a. mass moments by prefix sums ------------------------------------------------------------
@@ -532,7 +534,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         cogm[id] = p;
         bodies[id] = 1;
         ch[0] = order[k];  // tree.rs:532
-        rec[id] = NodeRec{p, k, 0u, 0u, 0u};  // walk: a leaf knows its body's sorted position
+        rec[id] = NodeRec{p, 0u, 0u, k, -1.0f};  // walk: a leaf knows its body's sorted position
     } else {
         const uint32_t d = dd;
         const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
@@ -565,64 +567,39 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         uint32_t first = 0, cnt = 0;
         for (int c = 7; c >= 0; --c)
             if (ch[c]) { first = ch[c]; ++cnt; }
-        rec[id] = NodeRec{q, first, cnt, 0u, 0u};
+        // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
+        // children were not all stored is walked as a single body of the cell's mass
+        if (cnt == 0u || first + cnt > n_nodes)
+            rec[id] = NodeRec{q, 0u, 0u, ~0u, -1.0f};
+        else
+            rec[id] = NodeRec{q, first, cnt, ~0u, 1.0f};
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
-// Stack entry: cell id (27 bits) | depth << 27, and the 64-bit mask of lanes that visit it.
+// Stack entry: the cell, its squared size (root_width^2 / 4^depth, exact powers of two as in
+// tree.wgsl:82) and the 64-bit mask of lanes that visit it.
 struct StackEntry {
-    uint32_t node_depth;
+    uint32_t node;
+    float size2;
     uint32_t mask_lo, mask_hi;
-    uint32_t pad;
 };
 constexpr uint32_t kWalkBatch = 4;  // cells popped (and fetched) together per iteration
-constexpr uint32_t kNodeBits = 27;  // 2^27 cells: 4N nodes for up to 33 M bodies
 
-// One cell against the wave's 64 bodies.  Returns the lanes that must open it.
-// Acceptance test size/dist < theta (tree.wgsl:63-64) in squared form, size^2 < theta^2 r^2:
-// no sqrt or reciprocal unless some lane accumulates the cell.
-template <bool COUNT>
-__device__ __forceinline__ uint64_t visit_cell(const float4 q, uint32_t first, uint32_t count,
-                                               uint32_t depth, bool mine, uint32_t my_pos, float xi,
-                                               float yi, float zi, float root_width, float theta2,
-                                               float e, float &ax, float &ay, float &az,
-                                               unsigned long long &visits,
-                                               unsigned long long &accepts) {
-    // size_stack: root_width halved `depth` times (exact: a power-of-two scaling, tree.wgsl:82)
-    const float size = root_width * __uint_as_float((127u - depth) << 23);
-    const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
-    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const bool leaf = count == 0u;  // wave-uniform
-    // a leaf is a body: always taken, except the body itself; a cell is taken when far enough
-    const bool far = leaf ? first != my_pos : size * size < theta2 * r2;
-    const bool take = mine && far;
-    const uint64_t open = leaf ? 0ull : __ballot(mine && !far);
-    if (take) {
-        const float dist = __builtin_amdgcn_sqrtf(r2);
-        const float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-        ax = __builtin_fmaf(w, dx, ax);
-        ay = __builtin_fmaf(w, dy, ay);
-        az = __builtin_fmaf(w, dz, az);
-    }
-    if (COUNT) {
-        visits += mine ? 1ull : 0ull;
-        accepts += take ? 1ull : 0ull;
-    }
-    return open;
-}
-
+// The loop is written to stay light on SCALAR work (the scalar unit is shared by the CU's four
+// SIMDs): no per-lane branches, a leaf and a cell take the same path (a leaf's record makes the
+// acceptance test always true and carries the one body position it must skip), the force is
+// predicated instead of branched around, and the stack cannot overflow by construction.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
-    const uint32_t *__restrict__ bound_bits,
-    const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, float4 *__restrict__ posm_dst,
-    float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst, uint32_t n, uint32_t lo, uint32_t hi,
-    float g, float e, float dt, float theta, uint32_t *__restrict__ status,
-    unsigned long long *__restrict__ counters) {
+    const uint32_t *__restrict__ bound_bits, const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
+    float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
+    uint32_t n, uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
+    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -645,58 +622,70 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
     if (n >= 2 && all) {
-        if (lane == 0) stack[0] = StackEntry{0u, (uint32_t)all, (uint32_t)(all >> 32), 0u};
+        if (lane == 0) stack[0] = StackEntry{0u, root_width * root_width, (uint32_t)all, (uint32_t)(all >> 32)};
         sp = 1;
     }
     __builtin_amdgcn_wave_barrier();
     // every cell is pushed at most once per wave; the bound makes a corrupt tree exit, not hang
     uint32_t budget = 2u * n_nodes + 64u;
     while (sp > 0) {
-        // pop up to kWalkBatch cells and fetch them together: their (wave-uniform, scalar)
-        // loads overlap instead of forming one dependent chain per cell
-        // (only while the stack has room for 4 x 8 children plus a pure depth-first descent
-        // below them; beyond that pop one cell at a time, which bounds growth by 7 per level)
+        // pop up to kWalkBatch cells and fetch them together: their (wave-uniform, scalar) loads
+        // overlap instead of forming one dependent chain per cell.  Only while the stack is
+        // shallow enough (see kWalkBatchMaxSp); beyond that one cell at a time, depth-first.
         const uint32_t nb = sp > kWalkBatchMaxSp ? 1u : (sp < kWalkBatch ? sp : kWalkBatch);
         if (budget <= nb) {
             if (lane == 0) atomicAdd(&status[3], 1u);
             break;
         }
         budget -= nb;
-        sp -= nb;
         if (COUNT) wave_cells += nb;
-        uint32_t e_node[kWalkBatch], e_depth[kWalkBatch], e_lo[kWalkBatch], e_hi[kWalkBatch];
+        // lane b fetches entry b (b = 0 is the top) -- one LDS instruction for the whole batch --
+        // and the fields are then read out of lanes 0..3
+        const StackEntry mine_e = stack[sp > lane ? sp - 1u - lane : 0u];
+        sp -= nb;
+        uint32_t e_node[kWalkBatch], e_lo[kWalkBatch], e_hi[kWalkBatch];
+        float e_size2[kWalkBatch];
         NodeRec r[kWalkBatch];
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
-            const StackEntry t = stack[sp + (b < nb ? nb - 1u - b : 0u)];  // b = 0 is the old top
-            // (the builtin returns a signed int: go through uint32_t or values sign-extend)
-            const uint32_t nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.node_depth);
-            e_node[b] = nd & ((1u << kNodeBits) - 1u);
-            e_depth[b] = nd >> kNodeBits;
-            e_lo[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask_lo);
-            e_hi[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.mask_hi);
+            // (the builtins return a signed int: go through uint32_t or values sign-extend)
+            e_node[b] = b < nb ? (uint32_t)__builtin_amdgcn_readlane((int)mine_e.node, b) : 0u;
+            e_size2[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine_e.size2), b));
+            e_lo[b] = (uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_lo, b);
+            e_hi[b] = (uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_hi, b);
         }
 #pragma unroll
-        for (uint32_t b = 0; b < kWalkBatch; ++b) r[b] = rec[e_node[b]];
+        for (uint32_t b = 0; b < kWalkBatch; ++b) r[b] = rec[e_node[b]];  // wave-uniform: s_load
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
             if (b >= nb) break;
+            const float4 q = r[b].cogm;
             const bool mine = ((e_lo[b] & lane_lo) | (e_hi[b] & lane_hi)) != 0u;
-            const uint64_t open = visit_cell<COUNT>(r[b].cogm, r[b].first, r[b].count, e_depth[b], mine,
-                                                    i, xi, yi, zi, root_width, theta2, e, ax, ay, az,
-                                                    visits, accepts);
+            const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
+            // negative size makes it always true, its self_pos excludes the body itself
+            const bool far = (e_size2[b] * r[b].size_sign < theta2 * r2) & (r[b].self_pos != i);
+            const bool take = mine & far;
+            const float dist = __builtin_amdgcn_sqrtf(r2);
+            float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
+            w = take ? w : 0.0f;  // predicated, not branched
+            ax = __builtin_fmaf(w, dx, ax);
+            ay = __builtin_fmaf(w, dy, ay);
+            az = __builtin_fmaf(w, dz, az);
+            if (COUNT) {
+                visits += mine ? 1ull : 0ull;
+                accepts += take ? 1ull : 0ull;
+            }
+            const uint32_t cnt = r[b].count;
+            const uint64_t open = cnt ? __ballot(mine & !far) : 0ull;
             if (open) {  // push the children (contiguous ids, octant order) for the opening lanes
-                const uint32_t cnt = r[b].count, first = r[b].first;
-                if (sp + cnt > kWalkStack || first + cnt > n_nodes) {
-                    if (lane == 0) atomicAdd(&status[0], 1u);
-                } else {
-                    if (lane < cnt)
-                        stack[sp + lane] = StackEntry{(first + lane) | ((e_depth[b] + 1u) << kNodeBits),
-                                                      (uint32_t)open, (uint32_t)(open >> 32), 0u};
-                    sp += cnt;
-                    if (COUNT) max_sp = sp > max_sp ? sp : max_sp;
-                }
+                if (lane < cnt)
+                    stack[sp + lane] = StackEntry{r[b].first + lane, e_size2[b] * 0.25f, (uint32_t)open,
+                                                  (uint32_t)(open >> 32)};
+                sp += cnt;
+                if (COUNT) max_sp = sp > max_sp ? sp : max_sp;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -762,7 +751,7 @@ class TreeSim final : public SimBase {
         }
         theta = add.theta > 0.f ? add.theta : NB_DEFAULT_THETA;
         const size_t nn = n ? n : 1;
-        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, (1u << kNodeBits) - 1u);  // 4N as tree.rs:188-190
+        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
         id_blocks = (uint32_t)((nn + kIdThreads - 1) / kIdThreads);
         scan_blocks = (uint32_t)((nn + kScanTile - 1) / kScanTile);
