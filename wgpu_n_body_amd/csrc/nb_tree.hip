@@ -30,8 +30,10 @@
 //                         wave-level stack of (node, lane mask) in LDS: a node is fetched once
 //                         per wave (wave-uniform address), every lane applies its OWN acceptance
 //                         test size/dist < theta, and children are pushed 0..7 for the lanes
-//                         that opened the node -- so each lane accumulates exactly the nodes,
-//                         in exactly the order, of the reference's per-thread walk.
+//                         that opened the node -- so each lane accumulates exactly the nodes of
+//                         the reference's per-thread walk (visit counts equal the oracle's).  Up
+//                         to four cells are popped and fetched per iteration, so the ORDER of a
+//                         lane's sum is not the reference's depth-first order (fp32 rounding).
 //
 // Deviations, all documented in DESIGN.md: bodies whose 63-bit keys collide (closer than
 // root_width/2^21) cannot be separated (the reference would recurse until its 4N-node buffer
