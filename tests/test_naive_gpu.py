@@ -381,3 +381,25 @@ def test_two_phase_step_on_one_rank_of_many(gpu, oracle):
     sim.encode()
     assert sim.step_num() == 2
     sim.destroy()
+
+
+def test_random_sizes_variants_and_splits_against_oracle(gpu, oracle):
+    """Fuzz: random body counts (ragged tiles, tails, tiny N), every kernel variant and forced
+    j-splits, all three inits -- each checked against the fp32 and fp64 oracles."""
+    nb = gpu
+    rng = np.random.default_rng(2024)
+    nvar = len(nb.naive_variants())
+    for it in range(36):
+        n = int(rng.choice([rng.integers(1, 70), rng.integers(70, 700), rng.integers(700, 6000)]))
+        kind = ["uniform", "spherical", "disc"][it % 3]
+        g, dt = (0.00001, 0.0016) if kind == "disc" else (G, DT)
+        variant = int(rng.integers(0, nvar))
+        jsplit = int(rng.choice([0, 1, 2, 3, 5, 8]))
+        s = make_state(kind, n, 4000 + it, g)
+        out = run_gpu(nb, s, 2, g=g, dt=dt, variant=variant, jsplit=jsplit)
+        ref32 = oracle.naive_run_f32(s, g, E, dt, 2)
+        ref64 = oracle.naive_run_f64(s, g, E, dt, 2)
+        try:
+            check_against_oracles(out, ref32, ref64, 2)
+        except AssertionError as ex:
+            raise AssertionError(f"n={n} kind={kind} variant={variant} jsplit={jsplit}: {ex}") from ex
