@@ -44,5 +44,5 @@ print(json.dumps({
     "bodies_per_s": args.bodies * args.steps / wall, "nodes": int(len(tree)),
     "visits_per_body_step1": float(c0[0]) / args.bodies, "accepted_per_body_step1": float(c0[1]) / args.bodies,
     "lane_visits_per_s": float(c0[0]) / (walk * 1e-3),
-    "cells_per_wave_step1": float(c0[2]) / ((args.bodies + 63) // 64), "stack_high_water": int(c0[3]),
+    "cells_per_wave_step1": float(c0[2]) / ((args.bodies + 63) // 64), "stack_high_water": int(c0[3]), "leaf_fraction_of_wave_cells": float(c0[4]) / float(c0[2]) if c0[2] else None,
     "lane_utilisation": float(c0[0]) / (64.0 * float(c0[2])) if c0[2] else None, "steps": args.steps, "warmup": args.warmup}))

@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float theta2 = theta * theta;
     const uint32_t lane_lo = lane < 32u ? 1u << lane : 0u, lane_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
     unsigned long long visits = 0, accepts = 0;
-    uint32_t wave_cells = 0, max_sp = 1;
+    uint32_t wave_cells = 0, wave_leaves = 0, max_sp = 1;
 
     StackEntry *stack = s_stack[wave];
     uint32_t sp = 0;
@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
             if (COUNT) {
                 visits += mine ? 1ull : 0ull;
                 accepts += take ? 1ull : 0ull;
+                if (r[b].count == 0u) wave_leaves += 1u;
             }
             const uint32_t cnt = r[b].count;
             const uint64_t open = cnt ? __ballot(mine & !far) : 0ull;
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     if (COUNT && lane == 0) {  // per-wave statistics: cells fetched, deepest stack
         atomicAdd(&counters[2], (unsigned long long)wave_cells);
         atomicMax(&counters[3], (unsigned long long)max_sp);
+        atomicAdd(&counters[4], (unsigned long long)wave_leaves);
     }
     if (!valid) return;
     const float gdt = g * dt;
@@ -794,9 +796,9 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
         if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&scalars, sizeof(uint32_t) * 64)) return rc;
-        if (int rc = alloc(&counters, sizeof(unsigned long long) * 4)) return rc;
+        if (int rc = alloc(&counters, sizeof(unsigned long long) * 8)) return rc;
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 64, stream));
-        NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 4, stream));
+        NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream));
         return write_particles(host, count);
     }
 
@@ -1056,7 +1058,7 @@ class TreeSim final : public SimBase {
         size_t len = 0;
         const std::string nm(name);
         if (nm == "order") { src = order; len = sizeof(uint32_t) * n; }
-        else if (nm == "counters") { src = counters; len = sizeof(unsigned long long) * 4; }
+        else if (nm == "counters") { src = counters; len = sizeof(unsigned long long) * 8; }
         else if (nm == "status") { src = scalars + 4; len = sizeof(uint32_t) * 4; }
         else if (nm == "depth_base") { src = scalars + 16; len = sizeof(uint32_t) * (kMaxDepth + 2); }
         else {
