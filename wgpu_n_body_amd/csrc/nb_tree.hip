@@ -20,7 +20,8 @@
 //                         neighbouring keys.  Node id = (#nodes of smaller depth) + rank among
 //                         the nodes of its depth in key order -- exactly the reference's BFS
 //                         allocation order (tree.rs:461,517-519; slice_alloc.rs:52-59).
-//   6 fill_kernel         per node: body range by binary search on the keys, children table
+//   6 fill_kernel         per node: body range by a galloping search on the keys; children = the
+//                         consecutive next-depth ids starting at the first body's own child
 //                         (0 = none; a leaf's children[0] = the body's source index, tree.rs:532)
 //   7 moments_kernel      mass / centre of gravity of every cell from binary64 prefix sums of
 //                         (m x, m y, m z, m) over the sorted bodies             tree.rs:486-505
@@ -522,9 +523,9 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ int_slot,
                             const uint32_t *__restrict__ leaf_id, const uint32_t *__restrict__ int_id,
                             const uint32_t *__restrict__ order, const float4 *__restrict__ posm,
-                            const Moments *__restrict__ mom, float4 *__restrict__ cogm,
-                            uint32_t *__restrict__ bodies, uint32_t *__restrict__ child,
-                            NodeRec *__restrict__ rec) {
+                            const Moments *__restrict__ mom, const uint32_t *__restrict__ depth_base,
+                            float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
+                            uint32_t *__restrict__ child, NodeRec *__restrict__ rec) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     if (id >= n_nodes) return;
@@ -540,23 +541,35 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     } else {
         const uint32_t d = dd;
         const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
-        const uint64_t prefix = d == 0 ? 0ull : (keys[k] >> shift);
-        const uint32_t end = d == 0 ? n : lower_bound_key(keys, k, n, (prefix + 1ull) << shift);
-        bodies[id] = end - k;
-        const uint32_t cshift = shift - 3u;
-        uint32_t b = k;
-        for (uint32_t c = 0; c < 8; ++c) {
-            const uint32_t e = c == 7 ? end
-                                      : lower_bound_key(keys, b, end, ((prefix << 3) + c + 1ull) << cshift);
-            if (e > b) {
-                if (e - b == 1) {
-                    ch[c] = leaf_id[b];
-                } else {  // internal cell of depth d+1 opened by body b
-                    const uint32_t slot = int_slot[b] + (d + 1u - (uint32_t)((int)cpl[b] + 1));
-                    ch[c] = slot < n_cap ? int_id[slot] : 0u;
-                }
+        // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
+        uint32_t end = n;
+        if (d != 0) {
+            const uint64_t limit = ((keys[k] >> shift) + 1ull) << shift;  // first key past the cell
+            uint32_t lo_s = k + 1u, off = 1u;
+            while (k + off < n && keys[k + off] < limit) {
+                lo_s = k + off + 1u;
+                off <<= 1;
             }
-            b = e;
+            end = lower_bound_key(keys, lo_s, min(k + off, n), limit);
+        }
+        bodies[id] = end - k;
+        // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
+        // (nodes of one depth are numbered in key order), starting with body k's own child
+        const int left = cpl[k], right = cpl[k + 1];
+        uint32_t f;
+        if ((int)d + 1 <= right) {  // body k also opens the cell one level down
+            const uint32_t slot = int_slot[k] + (d - (uint32_t)(left + 1) + 1u);
+            f = slot < n_cap ? int_id[slot] : ~0u;
+        } else {
+            f = leaf_id[k];
+        }
+        const uint32_t lim = min(depth_base[d + 2], n_nodes);  // end of the depth-(d+1) ids
+        for (uint32_t j = 0; j < 8u; ++j) {
+            const uint32_t cid = f + j;
+            if (f == ~0u || cid >= lim) break;
+            const uint32_t kc = node_first[cid];
+            if (j > 0 && kc >= end) break;
+            ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
         }
         // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
         const Moments a = mom[k], b2 = mom[end];
@@ -911,7 +924,7 @@ class TreeSim final : public SimBase {
         const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                           mom_prefix, cogm, bodies, child, rec);
+                           mom_prefix, depth_base, cogm, bodies, child, rec);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
