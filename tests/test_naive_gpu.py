@@ -302,8 +302,8 @@ def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world, jsplit):
     single.destroy()
 
 
-@pytest.mark.parametrize("mode", ["naive", "naive-overlap"])
-def test_sharded_naive_sim_two_ranks_one_gpu(gpu, oracle, tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("naive", 2), ("naive-overlap", 2), ("naive-overlap", 4)])
+def test_sharded_naive_sim_two_ranks_one_gpu(gpu, oracle, tmp_path, mode, world):
     """The product's multi-GPU class (ShardedNaiveSim: torch-owned position buffers, kernels on
     torch's stream, in-place all_gather_into_tensor) run as 2 processes sharing this one GPU,
     gloo standing in for RCCL.  Without overlap the step is the single simulator's, bit for bit;
@@ -314,7 +314,7 @@ def test_sharded_naive_sim_two_ranks_one_gpu(gpu, oracle, tmp_path, mode):
     import sys
     from tests.helpers import ROOT
     nb = gpu
-    n, steps, world = 3000, 3, 2
+    n, steps = 3000, 3
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
