@@ -19,6 +19,10 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--init", default="uniform")
 ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--cpu-baseline", action="store_true",
+                help="also time the CPU oracle: the reference's serial BFS build + DFS reorder "
+                     "(src/sims/tree.rs:417-602, single thread as in the reference) and the "
+                     "restated walk (OpenMP), on the same particles")
 args = ap.parse_args()
 
 sp = nb.SimParams(particle_num=args.bodies)
@@ -37,6 +41,27 @@ wall = time.perf_counter() - t0
 tree, rw = sim.read_tree()
 out = nb.as_floats(sim.dest_particle_slice())
 assert np.isfinite(out).all()
+cpu = None
+if args.cpu_baseline:
+    from oracle import oracle as O   # bench-only use of the checker, as a reported baseline
+    s0 = nb.as_floats(init)
+    t0 = time.perf_counter()
+    tree_ref, _rw = O.tree_build(s0)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    order_ref = O.tree_dfs_order(tree_ref, args.bodies)
+    sorted_ref = s0[order_ref]
+    t_sort = time.perf_counter() - t0
+    threads = min(O.max_threads(), 16)
+    O.set_threads(threads)
+    t0 = time.perf_counter()
+    O.tree_step_f32(s0, sp.g, sp.e, sp.dt, args.theta, flags=O.INTENDED)
+    t_step = time.perf_counter() - t0
+    cpu = {"kind": "port", "build_tree_s_1thread": t_build, "sort_particles_s_1thread": t_sort,
+           "full_step_s": t_step, "walk_threads": threads,
+           "note": "oracle restatement of tree.rs:417-602 (serial, as the reference) and of "
+                   "tree.wgsl (intended semantics, OpenMP); full_step includes build + reorder"}
+
 print(json.dumps({
     "metric": "Barnes-Hut step", "bodies": args.bodies, "theta": args.theta, "init": args.init,
     "ms_per_step": wall / args.steps * 1e3, "ms_per_step_events": tot / args.steps,
@@ -45,4 +70,4 @@ print(json.dumps({
     "visits_per_body_step1": float(c0[0]) / args.bodies, "accepted_per_body_step1": float(c0[1]) / args.bodies,
     "lane_visits_per_s": float(c0[0]) / (walk * 1e-3),
     "cells_per_wave_step1": float(c0[2]) / ((args.bodies + 63) // 64), "stack_high_water": int(c0[3]), "leaf_fraction_of_wave_cells": float(c0[4]) / float(c0[2]) if c0[2] else None,
-    "lane_utilisation": float(c0[0]) / (64.0 * float(c0[2])) if c0[2] else None, "steps": args.steps, "warmup": args.warmup}))
+    "lane_utilisation": float(c0[0]) / (64.0 * float(c0[2])) if c0[2] else None, "steps": args.steps, "warmup": args.warmup, "cpu_baseline": cpu}))
