@@ -266,7 +266,7 @@ def test_many_fresh_tree_sims_are_consistent(gpu):
         for rep in range(2):
             sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), init)
             if rep == 1:
-                sim.set_tuning("tree_use_graph", 0)     # eager launches must equal the hipGraph replay
+                sim.set_tuning("tree_use_graph", 1)     # the hipGraph replay must equal eager launches
             sim.encode()
             sim.encode()
             sim.wait()

@@ -831,9 +831,11 @@ class TreeSim final : public SimBase {
     }
 
     // TreeSim::encode, tree.rs:262-353 -- everything on the device, nothing mapped to the host.
-    // One step = ~60 small launches; they never change (same buffers, same arguments every
-    // step: the state lands back in buffer `cur`), so the sequence is captured into a hipGraph
-    // the first time and replayed afterwards -- one submission instead of sixty.
+    // One step = ~45 small launches that never change (same buffers, same arguments every step:
+    // the state lands back in buffer `cur`), so the sequence can be captured into a hipGraph once
+    // and replayed (tuning key "tree_use_graph").  Off by default: measured, the step is bound by
+    // the GPU-side cost of the dependent launches, not by their submission (8,192 bodies: 459 us
+    // eager vs 439 us replayed; no difference at 1 M), so the eager path is the one that ships.
     int encode() override {
         if (int rc = bind_device()) return rc;
         if (n == 0) {
@@ -1112,7 +1114,7 @@ class TreeSim final : public SimBase {
     uint32_t mom_blocks = 0;
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
-    bool count_visits = false, use_graph = true;
+    bool count_visits = false, use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;
