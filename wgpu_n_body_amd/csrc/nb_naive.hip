@@ -363,15 +363,23 @@ const Variant kVariants[] = {
     NB_V(4, 16, kSmem, true, 2),  // 16
     NB_V(2, 16, kSmem, true, 8),  // 17
     NB_V(2, 16, kLds, true, 4),   // 18
+    NB_V(4, 16, kLds, true, 1),   // 19
+    NB_V(4, 16, kLds, true, 4),   // 20
+    NB_V(8, 16, kLds, true, 1),   // 21
+    NB_V(8, 8, kLds, true, 1),    // 22
+    NB_V(4, 16, kLds, true, 8),   // 23
+    NB_V(4, 8, kLds, true, 8),    // 24
+    NB_V(2, 16, kLds, true, 16),  // 25
+    NB_V(4, 16, kSmem, true, 4),  // 26
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 // Default choice by the number of bodies this launch owns.  Measured on MI355X at N = 65536
-// (profiles/r01_variant_sweep*.txt): 4 bodies per lane, packed fp32, 16 waves per workgroup
-// (variant 14) is the fastest single-kernel shape at 256 workgroups; with fewer i-tiles than
+// (profiles/r01_variant_sweep*.txt): 4 bodies per lane, packed fp32, 16 waves per workgroup,
+// j loop unrolled 4x (variant 20) is the fastest single-kernel shape at 256 workgroups; with fewer i-tiles than
 // CUs the j range is additionally split over JS workgroups per i-tile so that >= ~256
 // workgroups (4 waves per SIMD on every CU) are in flight.
-constexpr int kAutoVariant = 14;
+constexpr int kAutoVariant = 20;  // ib4_w16 packed, j loop unrolled 4x
 constexpr uint32_t kTargetBlocks = 256;  // one 16-wave workgroup per CU
 constexpr uint32_t kMaxJSplit = 32;
 
