@@ -21,7 +21,7 @@
     } while (0)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kIters = 2000;
+constexpr int kIters = 4000;
 constexpr int kChains = 16;  // independent accumulators per lane
 constexpr int kRep = 4;      // chain sweeps per loop iteration
 
@@ -78,7 +78,10 @@ void run(const char *name, float *out, unsigned long long *cyc, int n_cu) {
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0));
         CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k<OP>, dim3(grid), dim3(threads), 0, 0, out, cyc, 1.0f);  // warm-up
+        // warm up for ~150 ms of back-to-back launches: the chip's clock needs ~50-100 ms under
+        // load to settle (profiles/r01_warmup.txt), and the costs below should be steady-state
+        for (int w = 0; w < 40 * (wps >= 4 ? 1 : 4 / wps); ++w)
+            hipLaunchKernelGGL(k<OP>, dim3(grid), dim3(threads), 0, 0, out, cyc, 1.0f);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
         hipLaunchKernelGGL(k<OP>, dim3(grid), dim3(threads), 0, 0, out, cyc, 1.0f);
