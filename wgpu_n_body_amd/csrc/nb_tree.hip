@@ -618,8 +618,15 @@ __global__ __launch_bounds__(256) void walk_kernel(
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    // this rank walks for the sorted bodies [lo, hi) (single GPU: [0, n))
-    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    // this rank walks for the sorted bodies [lo, hi) (single GPU: [0, n)).
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2); remap so that each
+    // XCD walks one contiguous eighth of the Morton-ordered bodies and its L2 keeps that region's
+    // deep cells instead of everybody's.  Speed only: any placement gives the same result.
+    const uint32_t per_xcd = gridDim.x / 8u, tail = gridDim.x - per_xcd * 8u;
+    uint32_t blk = blockIdx.x;
+    if (blk < per_xcd * 8u) blk = (blk & 7u) * per_xcd + (blk >> 3);   // bijective on [0, 8*per_xcd)
+    (void)tail;                                                        // the last < 8 blocks stay put
+    const uint32_t i = lo + blk * blockDim.x + threadIdx.x;
     const bool valid = i < hi;
     const uint32_t ic = valid ? i : hi - 1;
     const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
