@@ -178,8 +178,11 @@ int nb_sim_create_from_particles(nb_sim **out, const nb_sim_params *sim_params,
 int nb_sim_encode(nb_sim *sim);
 
 /* The same step in two halves, so that a multi-GPU caller can overlap the exchange of step k
- * with the beginning of step k+1 (all-pairs simulators with world > 1; otherwise phase 0 is a
- * no-op and phase 1 is nb_sim_encode):
+ * with the beginning of step k+1.
+ * TreeSim: phase 0 = bound, keys, sort, reorder of positions, octree build (needs positions and
+ * masses only); phase 1 = reorder of velocities/accelerations, walk + integrate.  A sharded host
+ * gathers positions first, enqueues phase 0, and lets the other two gathers run beside it.
+ * NaiveSim (world > 1; otherwise phase 0 is a no-op and phase 1 is nb_sim_encode):
  *   phase 0 -- interactions with the rank's OWN bodies.  Needs only this rank's slice of the
  *              current positions, so it may be enqueued right after the previous step, while
  *              the all-gather of the other slices is still in flight;

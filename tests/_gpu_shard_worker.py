@@ -2,7 +2,7 @@
 2-process run of the PRODUCT sharded path (wgpu_n_body_amd.sharded.ShardedNaiveSim: HIP local
 step + in-place all-gather through torch.distributed) with both ranks on cuda:0 and the gloo
 backend standing in for RCCL (RCCL refuses two ranks on one device).
-argv: out_dir n steps [naive|naive-overlap|tree]"""
+argv: out_dir n steps [naive|naive-overlap|tree|tree-overlap]"""
 import os
 import sys
 
@@ -25,8 +25,8 @@ def main():
     torch.cuda.set_device(0)
     sp = nb.SimParams(particle_num=n)
     init = nb.inits.uniform_init(sp, seed=77)
-    if mode == "tree":
-        sim = ShardedTreeSim(sp, 0.5, init, rank, world, 0)
+    if mode.startswith("tree"):
+        sim = ShardedTreeSim(sp, 0.5, init, rank, world, 0, overlap=(mode == "tree-overlap"))
         sim.lo, sim.hi = 0, n
     else:
         sim = ShardedNaiveSim(sp, init, rank, world, 0, variant=1, overlap=(mode == "naive-overlap"))

@@ -215,8 +215,9 @@ def test_full_size_tree_invariants_and_sampled_walk(gpu, oracle):
     assert np.array_equal(oracle.tree_dfs_order(ref_tree, n), order)
 
 
-@pytest.mark.parametrize("n,world", [(5000, 2), (3000, 3)])
-def test_sharded_tree_sim_ranks_on_one_gpu(gpu, tmp_path, n, world):
+@pytest.mark.parametrize("n,world,mode", [(5000, 2, "tree"), (3000, 3, "tree-overlap"),
+                                          (6000, 2, "tree-overlap")])
+def test_sharded_tree_sim_ranks_on_one_gpu(gpu, tmp_path, n, world, mode):
     """Multi-GPU Barnes-Hut, step 1 of SURVEY 8(e): replicated tree, partitioned walk, three
     in-place all-gathers (ShardedTreeSim).  `world` processes share this one GPU with gloo
     standing in for RCCL; every rank must end with the single simulator's state, bit for bit."""
@@ -235,7 +236,7 @@ def test_sharded_tree_sim_ranks_on_one_gpu(gpu, tmp_path, n, world):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
-             str(n), str(steps), "tree"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+             str(n), str(steps), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode(errors="replace")[-3000:]
@@ -305,3 +306,27 @@ def test_clustered_input_cannot_overflow_the_build(gpu):
         assert "nodes" in str(ex) or "stack" in str(ex) or "budget" in str(ex)
         assert status.any()
     sim.destroy()
+
+
+def test_tree_step_in_two_phases(gpu):
+    """nb_sim_encode_phase on a TreeSim: phase 0 (sort + build, positions only) then phase 1
+    (walk) is the same step as encode(), bit for bit; a second phase 0 in a row is an error."""
+    nb = gpu
+    s = make_state("uniform", 4000, 71)
+    sp = nb.SimParams(particle_num=4000)
+    a = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), s)
+    b = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), s)
+    for _ in range(3):
+        a.encode()
+        b.encode_phase(0)
+        b.encode_phase(1)
+    assert b.step_num() == 3
+    assert np.array_equal(a.dest_particle_slice(), b.dest_particle_slice())
+    b.encode_phase(0)
+    with pytest.raises(nb.NBodyError):
+        b.encode_phase(0)
+    b.encode()                       # completes the step whose first half is pending
+    a.encode()
+    assert np.array_equal(a.dest_particle_slice(), b.dest_particle_slice())
+    a.destroy()
+    b.destroy()

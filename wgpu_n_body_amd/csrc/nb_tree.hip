@@ -235,14 +235,21 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 }
 
 // ---- 4. gather into sorted (DFS) order ----------------------------------------------------------
-__global__ void gather_kernel(const uint32_t *__restrict__ order, uint32_t n,
-                              const float4 *__restrict__ posm_in, const float4 *__restrict__ vel_in,
-                              const float4 *__restrict__ acc_in, float4 *__restrict__ posm_out,
-                              float4 *__restrict__ vel_out, float4 *__restrict__ acc_out) {
+// positions/masses first (the build needs them), velocities/accelerations separately (only the
+// walk needs them): on several GPUs the second pair is still being all-gathered while the build runs
+__global__ void gather_posm_kernel(const uint32_t *__restrict__ order, uint32_t n,
+                                   const float4 *__restrict__ posm_in, float4 *__restrict__ posm_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    posm_out[k] = posm_in[order[k]];
+}
+
+__global__ void gather_va_kernel(const uint32_t *__restrict__ order, uint32_t n,
+                                 const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in,
+                                 float4 *__restrict__ vel_out, float4 *__restrict__ acc_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t s = order[k];
-    posm_out[k] = posm_in[s];
     vel_out[k] = vel_in[s];
     acc_out[k] = acc_in[s];
 }
@@ -829,6 +836,7 @@ class TreeSim final : public SimBase {
         }
         if (int rc = bind_device()) return rc;
         if (n == 0) return NB_OK;
+        build_done = false;  // a build enqueued for the old state is void
         NB_HIP_TRY(hipMemcpyAsync(d_aos, host, sizeof(nb_particle) * (size_t)n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(tree_aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_aos, n,
                            posm[cur], vel[cur], acc[cur]);
@@ -849,7 +857,7 @@ class TreeSim final : public SimBase {
             step_num += 1;
             return NB_OK;
         }
-        if (!use_graph || time_walk) {
+        if (!use_graph || time_walk || build_done) {
             if (int rc = enqueue_step()) return rc;
             step_num += 1;
             return NB_OK;
@@ -880,7 +888,44 @@ class TreeSim final : public SimBase {
         }
     }
 
+    // The step in two halves (nb_sim_encode_phase): the build needs only positions and masses,
+    // the walk also velocities and accelerations -- a multi-GPU host starts the build as soon as
+    // the position all-gather of the previous step has landed and lets the other two overlap it.
+    int encode_phase(int phase) override {
+        if (int rc = bind_device()) return rc;
+        if (phase != 0 && phase != 1) {
+            set_error("encode_phase: phase must be 0 or 1");
+            return NB_ERR_INVALID;
+        }
+        if (n == 0) {
+            if (phase == 1) step_num += 1;
+            return NB_OK;
+        }
+        if (phase == 0) {
+            if (build_done) {
+                set_error("encode_phase(0) called twice for one step");
+                return NB_ERR_INVALID;
+            }
+            if (int rc = enqueue_build()) return rc;
+            build_done = true;
+            return NB_OK;
+        }
+        if (!build_done)
+            if (int rc = enqueue_build()) return rc;
+        build_done = false;
+        if (int rc = enqueue_walk()) return rc;
+        step_num += 1;
+        return NB_OK;
+    }
+
     int enqueue_step() {
+        if (!build_done)
+            if (int rc = enqueue_build()) return rc;
+        build_done = false;
+        return enqueue_walk();
+    }
+
+    int enqueue_build() {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
         uint32_t *zero_word = scalars + 8;    // stays 0
@@ -907,8 +952,7 @@ class TreeSim final : public SimBase {
         uint64_t *skeys = keys[kb];
         order = idx[kb];
         // 4: the step's source, permuted into DFS/Morton order (tree.rs:297,315-325)
-        hipLaunchKernelGGL(gather_kernel, dim3(g256), b256, 0, stream, order, n, posm[s], vel[s], acc[s],
-                           posm[d], vel[d], acc[d]);
+        hipLaunchKernelGGL(gather_posm_kernel, dim3(g256), b256, 0, stream, order, n, posm[s], posm[d]);
         // 5: cells -> node ids
         hipLaunchKernelGGL(cpl_kernel, dim3(g256), b256, 0, stream, skeys, n, cpl, nint, status);
         hipLaunchKernelGGL(scan_sums_kernel, dim3(scan_blocks), b256, 0, stream, nint, n, scan_sums);
@@ -934,6 +978,16 @@ class TreeSim final : public SimBase {
         hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
                            mom_prefix, depth_base, cogm, bodies, child, rec);
+        NB_HIP_TRY(hipGetLastError());
+        return NB_OK;
+    }
+
+    int enqueue_walk() {
+        const int s = cur, d = cur ^ 1;
+        uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
+        const dim3 b256(256);
+        hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
+                           vel[d], acc[d]);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
@@ -1122,6 +1176,7 @@ class TreeSim final : public SimBase {
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false, use_graph = false;
+    bool build_done = false;  // phase 0 of the next step already enqueued
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;

@@ -188,21 +188,29 @@ class ShardedTreeSim:
     Every rank holds the full state, builds the identical octree (the build is deterministic)
     and walks only its contiguous range of the SORTED bodies; then the range's new positions,
     velocities and accelerations are all-gathered in place (three collectives: the next step
-    re-sorts all bodies, so all three arrays must be complete everywhere).  The tree build is
-    not sped up by more GPUs -- the spatial domain decomposition + LET exchange of the north
-    star is the next step."""
+    re-sorts all bodies, so all three arrays must be complete everywhere).
+
+    The build needs only positions and masses, so the step runs in two halves
+    (nb_sim_encode_phase) and the host loop is software-pipelined: positions are gathered
+    first, the NEXT step's sort + tree build is enqueued as soon as they have landed, and the
+    velocity/acceleration gathers run beside it; only the walk waits for them.
+
+    The tree build itself is not sped up by more GPUs -- the spatial domain decomposition +
+    LET exchange of the north star is the next step."""
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
-                 device_index: int, group=None):
+                 device_index: int, group=None, overlap: bool = True):
         import torch
         self._torch = torch
-        self.rank, self.world, self.group = rank, world, group
+        self.rank, self.world, self.group, self.overlap = rank, world, group, overlap
         self._dev = torch.device("cuda", device_index)
         self.stream = torch.cuda.Stream(self._dev)
         self.sim = TreeSim.from_particles(
             sim_params, AddParams.TreeSimParams(theta), as_particles(particles),
             Placement(device_index, rank, world, self.stream.cuda_stream))
         self._views = {}
+        self._works = []          # [positions, velocities, accelerations] gathers in flight
+        self._build_issued = False
         self.step_num = 0
 
     def _view(self, ptr: int, total_bytes: int):
@@ -212,27 +220,49 @@ class ShardedTreeSim:
             self._views[ptr] = t
         return t
 
+    def _wait(self, first: int, last: int) -> None:
+        """Order what is enqueued next after gathers first..last-1 (0 = positions)."""
+        for k in range(first, min(last, len(self._works))):
+            if self._works[k] is not None:
+                self._works[k].wait()
+                self._works[k] = None
+
     def encode(self) -> None:
         import torch.distributed as dist
         with self._torch.cuda.stream(self.stream):
-            self.sim.encode()
+            if not self._build_issued:
+                self._wait(0, 1)                  # positions complete
+                self.sim.encode_phase(0)          # bound, keys, sort, reorder, tree build
+            self._wait(0, 3)                      # velocities and accelerations complete
+            self.sim.encode_phase(1)              # reorder v/a, walk + integrate this rank's range
+            self._build_issued = False
+            self._works = []
             if self.world > 1:
-                for k in range(self.sim.exchange_count()):
+                for k in range(self.sim.exchange_count()):      # 0 positions, 1 vel, 2 acc
                     ptr, off, ln, tot = self.sim.exchange_region(k)
                     full = self._view(ptr, tot)
-                    dist.all_gather_into_tensor(full, full[off // 4:(off + ln) // 4], group=self.group)
+                    self._works.append(dist.all_gather_into_tensor(
+                        full, full[off // 4:(off + ln) // 4], group=self.group, async_op=True))
+                if self.overlap:
+                    self._wait(0, 1)              # next step's build, beside the v/a gathers
+                    self.sim.encode_phase(0)
+                    self._build_issued = True
         self.step_num += 1
 
     def cleanup(self) -> None:
         self.sim.cleanup()
 
     def wait(self) -> None:
+        with self._torch.cuda.stream(self.stream):
+            self._wait(0, 3)
         self.stream.synchronize()
 
     def read_particles(self) -> np.ndarray:
+        self.wait()
         self._torch.cuda.synchronize(self._dev)
         return self.sim.dest_particle_slice()
 
     def destroy(self) -> None:
+        self.wait()
         self._views.clear()
         self.sim.destroy()
