@@ -178,6 +178,7 @@ def main():
         per_rank = nb.shard_bodies_per_rank(n, world)
         local_pairs = min(per_rank, n) * (n - 1)              # pairs one launch evaluates
         achieved = FLOP_PER_PAIR * local_pairs / (ms_kernel * 1e-3) / 1e12
+        traffic = hbm_traffic_from_profile(n) if world == 1 else None
         out = {
             "metric": "body-pair interactions/sec, 64k-body all-pairs",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -192,7 +193,9 @@ def main():
                                           if args.variant is not None else "auto")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": hbm_traffic_from_profile(n) if world == 1 else None,
+                         "traffic": traffic,
+                         "hbm_gbps": (traffic / (ms_kernel * 1e-3) / 1e9) if traffic else None,
+                         "hbm_peak_gbps": 8000.0,
                          "kernel": "nb::naive_step_kernel", "kernel_ms": ms_kernel,
                          "flop_per_pair": FLOP_PER_PAIR,
                          "note": "compute-bound on FP32 VALU issue; 157.3 TFLOP/s is both the "
