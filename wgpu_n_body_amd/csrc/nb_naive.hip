@@ -371,6 +371,8 @@ const Variant kVariants[] = {
     NB_V(4, 8, kLds, true, 8),    // 24
     NB_V(2, 16, kLds, true, 16),  // 25
     NB_V(4, 16, kSmem, true, 4),  // 26
+    NB_V(2, 16, kSmem, true, 16), // 27
+    NB_V(2, 16, kSmem, true, 4),  // 28
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
