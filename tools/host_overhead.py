@@ -1,0 +1,59 @@
+"""Host-side cost of one sharded all-pairs step (the floor the N=8 strong-scaling point sits on).
+
+Runs ShardedNaiveSim on ONE GPU under the RCCL backend with world_size 1 and the collective
+forced on, with so few bodies that the kernels are shorter than the host work: the measured
+time per step is then the Python + ctypes + torch.distributed enqueue cost, which has to stay
+below the per-rank kernel time (164 us at 8 ranks x 8192 bodies) for the
+pipelined loop to keep the GPU busy.
+
+    python tools/host_overhead.py [--bodies 2048] [--steps 3000]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bodies", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=3000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import wgpu_n_body_amd as nb
+    from wgpu_n_body_amd.sharded import ShardedNaiveSim
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+    sp = nb.SimParams(particle_num=args.bodies, g=1e-6, e=1e-4, dt=0.016)
+    init = nb.inits.uniform_init(sp, seed=2)
+    for label, overlap, force in (("one launch, no collective", False, False),
+                                  ("two-phase, no collective", True, False),
+                                  ("one launch + all-gather", False, True),
+                                  ("two-phase + all-gather (the N>1 loop)", True, True)):
+        sim = ShardedNaiveSim(sp, init, 0, 1, 0, overlap=overlap)
+        sim.force_exchange = force
+        for _ in range(200):
+            sim.encode()
+        sim.wait()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sim.encode()
+        t_enq = time.perf_counter() - t0
+        sim.wait()
+        t_all = time.perf_counter() - t0
+        print(f"{label:40s} enqueue {t_enq / args.steps * 1e6:7.1f} us/step   "
+              f"enqueue+drain {t_all / args.steps * 1e6:7.1f} us/step", flush=True)
+        sim.destroy()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

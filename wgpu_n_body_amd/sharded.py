@@ -59,6 +59,7 @@ class ShardedStepper:
     """
 
     overlap = True
+    force_exchange = False    # issue the collective even at world == 1 (tools/host_overhead.py)
 
     def __init__(self, plan: ShardPlan, rank: int, posm, group=None):
         self.plan, self.rank, self.group = plan, rank, group
@@ -78,7 +79,7 @@ class ShardedStepper:
     def start_exchange(self, buf) -> None:
         """In-place all-gather: every rank contributes rows [rank*per, (rank+1)*per)."""
         import torch.distributed as dist
-        if self.plan.world == 1:
+        if self.plan.world == 1 and not self.force_exchange:
             return
         per = self.plan.per_rank
         mine = buf[self.rank * per:(self.rank + 1) * per]
@@ -107,7 +108,7 @@ class ShardedStepper:
         self.start_exchange(dst)
         self.cur ^= 1
         self.step_num += 1
-        if self.overlap and self.plan.world > 1:
+        if self.overlap and (self.plan.world > 1 or self.force_exchange):
             self._step_local(dst)              # next step's first half, beside the all-gather
             self._local_issued = True
 
