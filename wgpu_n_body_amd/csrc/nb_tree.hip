@@ -426,7 +426,8 @@ struct __attribute__((aligned(32))) NodeRec {
     float4 cogm;
     uint32_t first, count;  // children ids first .. first+count-1 (octant order); leaf: count 0
     uint32_t self_pos;      // leaf: sorted position of its body; cell: ~0 (matches no body)
-    float size_sign;        // cell: +1; leaf: -1, which makes "size^2 < theta^2 r^2" always true
+    float ssize2;           // cell: its squared size, root_width^2 / 4^depth (exact, tree.wgsl:82);
+                            // leaf: -1, which makes "size^2 < theta^2 r^2" always true
 };
 
 // ---- 6a. mass moments by prefix sums ------------------------------------------------------------
@@ -531,6 +532,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ leaf_id, const uint32_t *__restrict__ int_id,
                             const uint32_t *__restrict__ order, const float4 *__restrict__ posm,
                             const Moments *__restrict__ mom, const uint32_t *__restrict__ depth_base,
+                            const uint32_t *__restrict__ bound_bits,
                             float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
                             uint32_t *__restrict__ child, NodeRec *__restrict__ rec) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -591,21 +593,25 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             if (ch[c]) { first = ch[c]; ++cnt; }
         // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
         // children were not all stored is walked as a single body of the cell's mass
-        if (cnt == 0u || first + cnt > n_nodes)
+        if (cnt == 0u || first + cnt > n_nodes) {
             rec[id] = NodeRec{q, 0u, 0u, ~0u, -1.0f};
-        else
-            rec[id] = NodeRec{q, first, cnt, ~0u, 1.0f};
+        } else {
+            const float root_width = __uint_as_float(*bound_bits) * 2.0f;
+            float size2 = root_width * root_width;
+            for (uint32_t l = 0; l < d; ++l) size2 *= 0.25f;  // exact: the width halves per level
+            rec[id] = NodeRec{q, first, cnt, ~0u, size2};
+        }
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
-// Stack entry: the cell, its squared size (root_width^2 / 4^depth, exact powers of two as in
-// tree.wgsl:82) and the 64-bit mask of lanes that visit it.
+// Stack entry: the cell and the 64-bit mask of lanes that visit it (the cell's size travels in
+// its record).
 struct StackEntry {
     uint32_t node;
-    float size2;
+    uint32_t pad;
     uint32_t mask_lo, mask_hi;
 };
 constexpr uint32_t kWalkBatch = 4;  // cells popped (and fetched) together per iteration
@@ -641,9 +647,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
     float ax = 0.f, ay = 0.f, az = 0.f;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
-    const float root_width = __uint_as_float(*bound_bits) * 2.0f;
     const float theta2 = theta * theta;
-    const uint32_t lane_lo = lane < 32u ? 1u << lane : 0u, lane_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
     unsigned long long visits = 0, accepts = 0;
     uint32_t wave_cells = 0, wave_leaves = 0, max_sp = 1;
 
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
     if (n >= 2 && all) {
-        if (lane == 0) stack[0] = StackEntry{0u, root_width * root_width, (uint32_t)all, (uint32_t)(all >> 32)};
+        if (lane == 0) stack[0] = StackEntry{0u, 0u, (uint32_t)all, (uint32_t)(all >> 32)};
         sp = 1;
     }
     __builtin_amdgcn_wave_barrier();
@@ -672,16 +676,15 @@ __global__ __launch_bounds__(256) void walk_kernel(
         // and the fields are then read out of lanes 0..3
         const StackEntry mine_e = stack[sp > lane ? sp - 1u - lane : 0u];
         sp -= nb;
-        uint32_t e_node[kWalkBatch], e_lo[kWalkBatch], e_hi[kWalkBatch];
-        float e_size2[kWalkBatch];
+        uint32_t e_node[kWalkBatch];
+        uint64_t e_mask[kWalkBatch];
         NodeRec r[kWalkBatch];
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
             // (the builtins return a signed int: go through uint32_t or values sign-extend)
             e_node[b] = b < nb ? (uint32_t)__builtin_amdgcn_readlane((int)mine_e.node, b) : 0u;
-            e_size2[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine_e.size2), b));
-            e_lo[b] = (uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_lo, b);
-            e_hi[b] = (uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_hi, b);
+            e_mask[b] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_lo, b) |
+                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_hi, b) << 32);
         }
 #pragma unroll
         for (uint32_t b = 0; b < kWalkBatch; ++b) r[b] = rec[e_node[b]];  // wave-uniform: s_load
@@ -690,16 +693,17 @@ __global__ __launch_bounds__(256) void walk_kernel(
         for (uint32_t b = 0; b < kWalkBatch; ++b) {
             if (b >= nb) break;
             const float4 q = r[b].cogm;
-            const bool mine = ((e_lo[b] & lane_lo) | (e_hi[b] & lane_hi)) != 0u;
+            // the wave-uniform mask IS the lane predicate (no per-lane bit test)
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(e_mask[b]);
             const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
             const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
             // negative size makes it always true, its self_pos excludes the body itself
-            const bool far = (e_size2[b] * r[b].size_sign < theta2 * r2) & (r[b].self_pos != i);
+            const bool far = (r[b].ssize2 < theta2 * r2) & (r[b].self_pos != i);
             const bool take = mine & far;
             const float dist = __builtin_amdgcn_sqrtf(r2);
             float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-            w = take ? w : 0.0f;  // predicated, not branched
+            w = take ? w : 0.0f;  // predicated, not branched (skipping taker-less cells is slower)
             ax = __builtin_fmaf(w, dx, ax);
             ay = __builtin_fmaf(w, dy, ay);
             az = __builtin_fmaf(w, dz, az);
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
             const uint64_t open = cnt ? __ballot(mine & !far) : 0ull;
             if (open) {  // push the children (contiguous ids, octant order) for the opening lanes
                 if (lane < cnt)
-                    stack[sp + lane] = StackEntry{r[b].first + lane, e_size2[b] * 0.25f, (uint32_t)open,
+                    stack[sp + lane] = StackEntry{r[b].first + lane, 0u, (uint32_t)open,
                                                   (uint32_t)(open >> 32)};
                 sp += cnt;
                 if (COUNT) max_sp = sp > max_sp ? sp : max_sp;
@@ -977,7 +981,7 @@ class TreeSim final : public SimBase {
         const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                           mom_prefix, depth_base, cogm, bodies, child, rec);
+                           mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
         NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }
