@@ -53,10 +53,9 @@ constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
 constexpr uint32_t kIdThreads = 256;
-constexpr uint32_t kWalkStack = 320;   // wave-level stack entries (16 B each): 5 KiB per wave
-// batch-pop only while sp <= this: 4 x 7 net pushes + 7 per level of a depth-first descent
-// over 21 levels still fit (140 + 28 + 147 <= 320), so the stack cannot overflow
-constexpr uint32_t kWalkBatchMaxSp = 140;
+// wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
+// most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
+constexpr uint32_t kWalkStack = 192;
 
 __device__ __forceinline__ float kick(float v, float a, float dt) {
 #pragma clang fp contract(off)
@@ -607,24 +606,75 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
-// Stack entry: the cell and the 64-bit mask of lanes that visit it (the cell's size travels in
-// its record).
+// Stack entry: a SIBLING GROUP -- the children first .. first+count-1 of one opened cell (their
+// ids are consecutive, octant order) -- and the 64-bit mask of the lanes that opened it.  One
+// entry per opened cell instead of one per child: a third of the LDS traffic and of the
+// lane-0 read-outs, and the children's records sit back to back in memory.
 struct StackEntry {
-    uint32_t node;
-    uint32_t pad;
+    uint32_t first, count;
     uint32_t mask_lo, mask_hi;
 };
-constexpr uint32_t kWalkBatch = 4;  // cells popped (and fetched) together per iteration
+constexpr uint32_t kWalkBatch = 4;  // records fetched together (a group is 1..8 cells)
 
-// The loop is written to stay light on SCALAR work (the scalar unit is shared by the CU's four
-// SIMDs): no per-lane branches, a leaf and a cell take the same path (a leaf's record makes the
-// acceptance test always true and carries the one body position it must skip), the force is
-// predicated instead of branched around, and the stack cannot overflow by construction.
+struct WalkStats {
+    unsigned long long visits = 0, accepts = 0;
+    uint32_t wave_cells = 0, wave_leaves = 0, max_sp = 1;
+};
+
+// K consecutive cells of one sibling group: their records are fetched together (wave-uniform
+// address + immediate offsets: scalar loads), then each is tested and accumulated by every
+// lane.  Straight-line per K so that no per-cell loop control or index clamping is needed, and
+// light on SCALAR work (the scalar unit is what the loop saturates first): no per-lane
+// branches, a leaf and a cell take the same path (a leaf's record makes the acceptance test
+// always true and carries the one body position it must skip), the force is predicated
+// instead of branched around, and the lane sets are 64-bit masks combined by s_and/s_andn2.
+template <uint32_t K, bool COUNT>
+__device__ __forceinline__ void walk_cells(const NodeRec *__restrict__ rp, uint64_t gmask, uint32_t i,
+                                           float xi, float yi, float zi, float theta2, float e,
+                                           float &ax, float &ay, float &az, StackEntry *stack,
+                                           uint32_t &sp, bool lane0, WalkStats &st) {
+    NodeRec r[K];
+#pragma unroll
+    for (uint32_t b = 0; b < K; ++b) r[b] = rp[b];
+#pragma unroll
+    for (uint32_t b = 0; b < K; ++b) {
+        const float4 q = r[b].cogm;
+        const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
+        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
+        // negative size makes it always true, its self_pos excludes the body itself
+        const uint64_t far = __ballot(r[b].ssize2 < theta2 * r2);
+        const uint64_t other = __ballot(r[b].self_pos != i);
+        const uint64_t take = gmask & far & other;
+        const uint64_t open = gmask & ~far;  // never a leaf: its test is always true
+        const float dist = __builtin_amdgcn_sqrtf(r2);
+        float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
+        w = __builtin_amdgcn_inverse_ballot_w64(take) ? w : 0.0f;  // predicated, not branched
+        ax = __builtin_fmaf(w, dx, ax);
+        ay = __builtin_fmaf(w, dy, ay);
+        az = __builtin_fmaf(w, dz, az);
+        if (COUNT) {
+            st.visits += __builtin_amdgcn_inverse_ballot_w64(gmask) ? 1ull : 0ull;
+            st.accepts += __builtin_amdgcn_inverse_ballot_w64(take) ? 1ull : 0ull;
+            if (r[b].count == 0u) st.wave_leaves += 1u;
+        }
+        if (open) {  // push the cell's children as one group for the opening lanes
+            if (lane0)
+                stack[sp] = StackEntry{r[b].first, r[b].count, (uint32_t)open, (uint32_t)(open >> 32)};
+            sp += 1;
+            if (COUNT) st.max_sp = sp > st.max_sp ? sp : st.max_sp;
+        }
+    }
+}
+
+// One wave walks for 64 consecutive sorted bodies, depth-first over sibling groups: a pop
+// pushes at most 8 groups one level down, so the stack holds at most 7 x 21 + 1 entries -- it
+// cannot overflow.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
-    const uint32_t *__restrict__ bound_bits, const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
+    const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t n, uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
@@ -635,10 +685,10 @@ __global__ __launch_bounds__(256) void walk_kernel(
     // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2); remap so that each
     // XCD walks one contiguous eighth of the Morton-ordered bodies and its L2 keeps that region's
     // deep cells instead of everybody's.  Speed only: any placement gives the same result.
-    const uint32_t per_xcd = gridDim.x / 8u, tail = gridDim.x - per_xcd * 8u;
+    const uint32_t per_xcd = gridDim.x / 8u;
     uint32_t blk = blockIdx.x;
     if (blk < per_xcd * 8u) blk = (blk & 7u) * per_xcd + (blk >> 3);   // bijective on [0, 8*per_xcd)
-    (void)tail;                                                        // the last < 8 blocks stay put
+                                                                       // the last < 8 blocks stay put
     const uint32_t i = lo + blk * blockDim.x + threadIdx.x;
     const bool valid = i < hi;
     const uint32_t ic = valid ? i : hi - 1;
@@ -648,86 +698,49 @@ __global__ __launch_bounds__(256) void walk_kernel(
     float ax = 0.f, ay = 0.f, az = 0.f;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     const float theta2 = theta * theta;
-    unsigned long long visits = 0, accepts = 0;
-    uint32_t wave_cells = 0, wave_leaves = 0, max_sp = 1;
+    WalkStats st;
+    const bool lane0 = lane == 0u;
 
     StackEntry *stack = s_stack[wave];
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
     if (n >= 2 && all) {
-        if (lane == 0) stack[0] = StackEntry{0u, 0u, (uint32_t)all, (uint32_t)(all >> 32)};
+        if (lane0) stack[0] = StackEntry{0u, 1u, (uint32_t)all, (uint32_t)(all >> 32)};  // the root
         sp = 1;
     }
     __builtin_amdgcn_wave_barrier();
-    // every cell is pushed at most once per wave; the bound makes a corrupt tree exit, not hang
-    uint32_t budget = 2u * n_nodes + 64u;
+    // every cell is opened at most once per wave; the bound makes a corrupt tree exit, not hang
+    uint32_t budget = n_nodes + 64u;
     while (sp > 0) {
-        // pop up to kWalkBatch cells and fetch them together: their (wave-uniform, scalar) loads
-        // overlap instead of forming one dependent chain per cell.  Only while the stack is
-        // shallow enough (see kWalkBatchMaxSp); beyond that one cell at a time, depth-first.
-        const uint32_t nb = sp > kWalkBatchMaxSp ? 1u : (sp < kWalkBatch ? sp : kWalkBatch);
-        if (budget <= nb) {
-            if (lane == 0) atomicAdd(&status[3], 1u);
+        if (budget == 0u || sp > kWalkStack - 8u) {
+            if (lane0) atomicAdd(&status[3], 1u);
             break;
         }
-        budget -= nb;
-        if (COUNT) wave_cells += nb;
-        // lane b fetches entry b (b = 0 is the top) -- one LDS instruction for the whole batch --
-        // and the fields are then read out of lanes 0..3
-        const StackEntry mine_e = stack[sp > lane ? sp - 1u - lane : 0u];
-        sp -= nb;
-        uint32_t e_node[kWalkBatch];
-        uint64_t e_mask[kWalkBatch];
-        NodeRec r[kWalkBatch];
-#pragma unroll
-        for (uint32_t b = 0; b < kWalkBatch; ++b) {
-            // (the builtins return a signed int: go through uint32_t or values sign-extend)
-            e_node[b] = b < nb ? (uint32_t)__builtin_amdgcn_readlane((int)mine_e.node, b) : 0u;
-            e_mask[b] = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_lo, b) |
-                        ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)mine_e.mask_hi, b) << 32);
-        }
-#pragma unroll
-        for (uint32_t b = 0; b < kWalkBatch; ++b) r[b] = rec[e_node[b]];  // wave-uniform: s_load
+        --budget;
+        --sp;
+        const StackEntry top = stack[sp];  // every lane reads the same entry (LDS broadcast)
+        // (the builtin returns a signed int: go through uint32_t or values sign-extend)
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)top.first);
+        const uint32_t gcnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)top.count);
+        const uint64_t gmask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)top.mask_lo) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)top.mask_hi) << 32);
+        if (COUNT) st.wave_cells += gcnt;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (uint32_t b = 0; b < kWalkBatch; ++b) {
-            if (b >= nb) break;
-            const float4 q = r[b].cogm;
-            // the wave-uniform mask IS the lane predicate (no per-lane bit test)
-            const bool mine = __builtin_amdgcn_inverse_ballot_w64(e_mask[b]);
-            const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
-            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
-            // negative size makes it always true, its self_pos excludes the body itself
-            const bool far = (r[b].ssize2 < theta2 * r2) & (r[b].self_pos != i);
-            const bool take = mine & far;
-            const float dist = __builtin_amdgcn_sqrtf(r2);
-            float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-            w = take ? w : 0.0f;  // predicated, not branched (skipping taker-less cells is slower)
-            ax = __builtin_fmaf(w, dx, ax);
-            ay = __builtin_fmaf(w, dy, ay);
-            az = __builtin_fmaf(w, dz, az);
-            if (COUNT) {
-                visits += mine ? 1ull : 0ull;
-                accepts += take ? 1ull : 0ull;
-                if (r[b].count == 0u) wave_leaves += 1u;
-            }
-            const uint32_t cnt = r[b].count;
-            const uint64_t open = cnt ? __ballot(mine & !far) : 0ull;
-            if (open) {  // push the children (contiguous ids, octant order) for the opening lanes
-                if (lane < cnt)
-                    stack[sp + lane] = StackEntry{r[b].first + lane, 0u, (uint32_t)open,
-                                                  (uint32_t)(open >> 32)};
-                sp += cnt;
-                if (COUNT) max_sp = sp > max_sp ? sp : max_sp;
+        for (uint32_t c0 = 0; c0 < gcnt; c0 += kWalkBatch) {
+            const NodeRec *rp = rec + first + c0;
+            switch (gcnt - c0) {
+            case 1: walk_cells<1, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
+            case 2: walk_cells<2, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
+            case 3: walk_cells<3, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
+            default: walk_cells<4, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (COUNT && lane == 0) {  // per-wave statistics: cells fetched, deepest stack
-        atomicAdd(&counters[2], (unsigned long long)wave_cells);
-        atomicMax(&counters[3], (unsigned long long)max_sp);
-        atomicAdd(&counters[4], (unsigned long long)wave_leaves);
+    if (COUNT && lane0) {  // per-wave statistics: cells fetched, deepest stack
+        atomicAdd(&counters[2], (unsigned long long)st.wave_cells);
+        atomicMax(&counters[3], (unsigned long long)st.max_sp);
+        atomicAdd(&counters[4], (unsigned long long)st.wave_leaves);
     }
     if (!valid) return;
     const float gdt = g * dt;
@@ -736,8 +749,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
     vel_dst[i] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
     acc_dst[i] = float4{fx, fy, fz, 0.f};
     if (COUNT) {
-        atomicAdd(&counters[0], visits);
-        atomicAdd(&counters[1], accepts);
+        atomicAdd(&counters[0], st.visits);
+        atomicAdd(&counters[1], st.accepts);
     }
 }
 
@@ -988,7 +1001,7 @@ class TreeSim final : public SimBase {
 
     int enqueue_walk() {
         const int s = cur, d = cur ^ 1;
-        uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
+        uint32_t *n_nodes = scalars + 1, *status = scalars + 4;
         const dim3 b256(256);
         hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
                            vel[d], acc[d]);
@@ -998,11 +1011,11 @@ class TreeSim final : public SimBase {
             const dim3 gwalk((hi - lo + 255) / 256);
             if (count_visits)
                 hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
             else
                 hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   bound_bits, n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
