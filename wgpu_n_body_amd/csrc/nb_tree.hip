@@ -592,7 +592,9 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             if (ch[c]) { first = ch[c]; ++cnt; }
         // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
         // children were not all stored is walked as a single body of the cell's mass
-        if (cnt == 0u || first + cnt > n_nodes) {
+        // ... and children always carry larger ids than their parent (breadth-first numbering), which
+        // is what lets the walk terminate without a visit budget: enforce it here
+        if (cnt == 0u || first + cnt > n_nodes || first <= id) {
             rec[id] = NodeRec{q, 0u, 0u, ~0u, -1.0f};
         } else {
             const float root_width = __uint_as_float(*bound_bits) * 2.0f;
@@ -696,7 +698,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
     float ax = 0.f, ay = 0.f, az = 0.f;
-    const uint32_t n_nodes = min(*n_nodes_p, n_cap);
+    (void)n_nodes_p;
+    (void)n_cap;
     const float theta2 = theta * theta;
     WalkStats st;
     const bool lane0 = lane == 0u;
@@ -709,14 +712,13 @@ __global__ __launch_bounds__(256) void walk_kernel(
         sp = 1;
     }
     __builtin_amdgcn_wave_barrier();
-    // every cell is opened at most once per wave; the bound makes a corrupt tree exit, not hang
-    uint32_t budget = n_nodes + 64u;
+    // Termination: a group's children have larger ids than their parent (fill_kernel enforces
+    // it), so no cell is reached twice; the stack check only guards against a corrupt tree.
     while (sp > 0) {
-        if (budget == 0u || sp > kWalkStack - 8u) {
+        if (sp > kWalkStack - 8u) {
             if (lane0) atomicAdd(&status[3], 1u);
             break;
         }
-        --budget;
         --sp;
         const StackEntry top = stack[sp];  // every lane reads the same entry (LDS broadcast)
         // (the builtin returns a signed int: go through uint32_t or values sign-extend)
@@ -728,12 +730,15 @@ __global__ __launch_bounds__(256) void walk_kernel(
         __builtin_amdgcn_wave_barrier();
         for (uint32_t c0 = 0; c0 < gcnt; c0 += kWalkBatch) {
             const NodeRec *rp = rec + first + c0;
-            switch (gcnt - c0) {
-            case 1: walk_cells<1, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
-            case 2: walk_cells<2, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
-            case 3: walk_cells<3, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
-            default: walk_cells<4, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st); break;
-            }
+            const uint32_t rem = gcnt - c0;
+            if (rem >= 4u)
+                walk_cells<4, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+            else if (rem == 3u)
+                walk_cells<3, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+            else if (rem == 2u)
+                walk_cells<2, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+            else
+                walk_cells<1, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
         }
         __builtin_amdgcn_wave_barrier();
     }
