@@ -191,6 +191,26 @@ int nb_sim_encode(nb_sim *sim);
  * nb_sim_encode after a phase 0 completes that step (= phase 1). */
 int nb_sim_encode_phase(nb_sim *sim, int phase);
 
+/* Multi-GPU Barnes-Hut with locally essential trees (LET; no reference counterpart -- the
+ * reference has one device).  Every rank creates a TreeSim over ITS OWN bodies (placement world 1),
+ * then sets the tuning keys "tree_let_world", "tree_let_rank" and "tree_let_cap" (records a peer
+ * may receive from this rank; allocates the buffers).  One step is three phases with an exchange
+ * after the first two (regions are those of nb_sim_exchange_region_i):
+ *   NB_PHASE_LET_META   local bound + bounding box of the drifted bodies -> region 0;
+ *                       caller: all-gather region 0 in place (32 B per rank)
+ *   NB_PHASE_LET_BUILD  global root cube, octree of the rank's bodies, and for every peer the part
+ *                       of that octree the peer's box can reach (32-byte records, children
+ *                       contiguous, links relative to the segment) -> region 2, counts -> region 1;
+ *                       caller: all-gather region 1 (`world` u32 per rank), read it, move
+ *                       counts[r][me] records of rank r's segment `me` into region 3 packed in rank
+ *                       order, then nb_sim_let_set_imports(counts received from each rank)
+ *   NB_PHASE_LET_WALK   walk own tree + imported trees, integrate.
+ * Walking an imported tree gives bit for bit what walking the peer's whole octree would give. */
+#define NB_PHASE_LET_META 2
+#define NB_PHASE_LET_BUILD 3
+#define NB_PHASE_LET_WALK 4
+int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world);
+
 /* `Simulator::cleanup(&mut self)`, src/sims/mod.rs:87-89 (TreeSim resets its
  * arena, src/sims/tree.rs:363-365).  Host-side housekeeping that may overlap
  * the enqueued step.  No-op for the all-pairs simulator. */

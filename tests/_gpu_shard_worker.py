@@ -2,7 +2,9 @@
 2-process run of the PRODUCT sharded path (wgpu_n_body_amd.sharded.ShardedNaiveSim: HIP local
 step + in-place all-gather through torch.distributed) with both ranks on cuda:0 and the gloo
 backend standing in for RCCL (RCCL refuses two ranks on one device).
-argv: out_dir n steps [naive|naive-overlap|tree|tree-overlap]"""
+argv: out_dir n steps [naive|naive-overlap|tree|tree-overlap|let]
+"let": the LET Barnes-Hut class (LetTreeSim) for tests/test_let_gpu.py; writes rank<r>.npy with
+the rank's own bodies."""
 import os
 import sys
 
@@ -14,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import wgpu_n_body_amd as nb  # noqa: E402
-from wgpu_n_body_amd.sharded import ShardedNaiveSim, ShardedTreeSim  # noqa: E402
+from wgpu_n_body_amd.sharded import LetTreeSim, ShardedNaiveSim, ShardedTreeSim  # noqa: E402
 
 
 def main():
@@ -24,6 +26,18 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     sp = nb.SimParams(particle_num=n)
+    if mode == "let":
+        init = nb.inits.uniform_init(sp, seed=27).copy()   # = tests/test_let_gpu.py::tagged(nb, n, 27)
+        nb.as_floats(init)[:, 9] = 1.0 + np.arange(n, dtype=np.float32) / np.float32(2 * n)
+        sim = LetTreeSim(sp, 0.5, init, rank, world, 0)
+        for _ in range(steps):
+            sim.encode()
+            sim.cleanup()
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), nb.as_floats(sim.read_local()))
+        dist.barrier()
+        sim.destroy()
+        dist.destroy_process_group()
+        return
     init = nb.inits.uniform_init(sp, seed=77)
     if mode.startswith("tree"):
         sim = ShardedTreeSim(sp, 0.5, init, rank, world, 0, overlap=(mode == "tree-overlap"))

@@ -1,0 +1,265 @@
+"""Multi-GPU Barnes-Hut with locally essential trees (LET): the device side of the protocol
+(nb_sim_encode_phase(NB_PHASE_LET_*), nb_sim_let_set_imports) driven here by `world` simulators
+sharing one GPU, the all-gathers and the all-to-all done with device-to-device copies -- what
+RCCL does across GPUs -- plus the product class LetTreeSim run as separate processes.
+
+What a body feels under LET is the sum of per-domain Barnes-Hut walks.  That is not the single
+octree's approximation (cells are cut along domain borders), so against the single TreeSim the
+comparison is at the level of the method's own error; the exact statements tested are:
+  * world = 1: the protocol is the single TreeSim, bit for bit;
+  * pruning is decision-exact: exporting whole octrees instead of LETs changes no bit;
+  * theta -> 0: all-pairs (oracle), to fp32 summation tolerance;
+  * the force error against all-pairs is that of the single tree."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT, bits
+
+pytestmark = pytest.mark.gpu
+
+META, BUILD, WALK = 2, 3, 4
+REC = 32  # bytes per exported record
+
+
+def _hip():
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            lib = C.CDLL(name)
+            lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            return lib
+        except OSError:
+            continue
+    raise RuntimeError("libamdhip64 not found")
+
+
+def tagged(nb, n, seed, init="uniform"):
+    """Seeded particles whose masses are distinct, so bodies can be matched after the sims have
+    re-ordered them (every tree step leaves the bodies in tree order, like the reference)."""
+    sp = nb.SimParams(particle_num=n)
+    p = getattr(nb.inits, init + "_init")(sp, seed=seed).copy()
+    f = nb.as_floats(p)
+    f[:, 9] = 1.0 + np.arange(n, dtype=np.float32) / np.float32(2 * n)
+    return sp, p
+
+
+def by_tag(nb, particles):
+    f = nb.as_floats(particles)
+    return f[np.argsort(f[:, 9], kind="stable")]
+
+
+class LetGroup:
+    """`world` TreeSims on one GPU running the LET protocol, exchanges by hipMemcpy."""
+
+    def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None):
+        from wgpu_n_body_amd.sharded import morton_order
+        self.nb, self.world, self.hip = nb, world, _hip()
+        order = morton_order(particles)
+        cuts = [(len(order) * r) // world for r in range(world + 1)]
+        self.sims = []
+        for r in range(world):
+            mine = np.ascontiguousarray(particles[order[cuts[r]:cuts[r + 1]]])
+            spl = nb.SimParams(particle_num=len(mine), g=sp.g, e=sp.e, dt=sp.dt)
+            s = nb.TreeSim.from_particles(spl, nb.AddParams.TreeSimParams(theta), mine)
+            s.set_tuning("tree_let_world", world)
+            s.set_tuning("tree_let_rank", r)
+            s.set_tuning("tree_let_prune", 1 if prune else 0)
+            s.set_tuning("tree_let_cap", cap or (2 * len(mine) + 64))
+            self.sims.append(s)
+        self.cap = [cap or (2 * (cuts[r + 1] - cuts[r]) + 64) for r in range(world)]
+        self.counts = None
+
+    def _copy(self, dst, src, nbytes):
+        if nbytes:
+            assert self.hip.hipMemcpy(dst, src, nbytes, 3) == 0  # device to device
+
+    def _all_gather(self, k):
+        regs = []
+        for s in self.sims:
+            s.wait()
+            regs.append(s.exchange_region(k))
+        for src, (sp_, off, ln, _t) in enumerate(regs):
+            for dst, (dp_, _o, _l, _t2) in enumerate(regs):
+                if dst != src:
+                    self._copy(dp_ + off, sp_ + off, ln)
+
+    def step(self):
+        W = self.world
+        for s in self.sims:
+            s.encode_phase(META)
+        self._all_gather(0)
+        for s in self.sims:
+            s.encode_phase(BUILD)
+        self._all_gather(1)
+        # the counts matrix, read on the "host" of rank 0 (identical everywhere after the gather)
+        ptr, _o, _l, tot = self.sims[0].exchange_region(1)
+        host = np.zeros(W * W, dtype=np.uint32)
+        assert self.hip.hipMemcpy(host.ctypes.data, ptr, tot, 2) == 0
+        counts = host.reshape(W, W).astype(np.int64)
+        self.counts = counts
+        for me, s in enumerate(self.sims):          # all-to-all: segment `me` of every peer
+            rptr = s.exchange_region(3)[0]
+            offs = 0
+            recv = []
+            for r in range(W):
+                c = 0 if r == me else int(counts[r, me])
+                recv.append(c)
+                if c:
+                    sptr, _o, seg, _t = self.sims[r].exchange_region(2)
+                    self._copy(rptr + offs * REC, sptr + me * seg, c * REC)
+                offs += c
+            s.let_set_imports(recv)
+        for s in self.sims:
+            s.encode_phase(WALK)
+
+    def particles(self):
+        return np.concatenate([s.dest_particle_slice() for s in self.sims])
+
+    def destroy(self):
+        for s in self.sims:
+            s.destroy()
+
+
+def test_let_protocol_with_one_rank_is_the_single_tree_sim(gpu):
+    nb = gpu
+    sp, p = tagged(nb, 5000, 21)
+    single = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), p)
+    grp = LetGroup(nb, sp, p, 1, 0.5)
+    for _ in range(3):
+        single.encode()
+        grp.step()
+    a, b = by_tag(nb, single.dest_particle_slice()), by_tag(nb, grp.particles())
+    assert np.array_equal(bits(a), bits(b))
+    single.destroy()
+    grp.destroy()
+
+
+@pytest.mark.parametrize("n,world,theta,init", [(6000, 2, 0.5, "uniform"), (9000, 3, 0.75, "uniform"),
+                                                 (20000, 4, 0.5, "uniform"), (8000, 3, 0.6, "disc")])
+def test_let_pruning_changes_no_bit(gpu, n, world, theta, init):
+    """Exporting each rank's WHOLE octree to every peer and exporting only the locally essential
+    part must give identical bodies: the pruning never alters a decision of the walk."""
+    nb = gpu
+    sp, p = tagged(nb, n, 22, init)
+    pruned = LetGroup(nb, sp, p, world, theta, prune=True)
+    whole = LetGroup(nb, sp, p, world, theta, prune=False)
+    for _ in range(3):
+        pruned.step()
+        whole.step()
+    a, b = by_tag(nb, pruned.particles()), by_tag(nb, whole.particles())
+    assert np.isfinite(a).all()
+    assert np.array_equal(bits(a), bits(b))
+    off = ~np.eye(world, dtype=bool)
+    assert (pruned.counts[off] <= whole.counts[off]).all()
+    # ... and it does prune (least for the thin disc, whose Morton domains interleave)
+    assert pruned.counts[off].sum() < (0.8 if init == "disc" else 0.7) * whole.counts[off].sum()
+    pruned.destroy()
+    whole.destroy()
+
+
+def test_let_with_theta_to_zero_is_all_pairs(gpu, oracle):
+    nb = gpu
+    n, world = 3000, 3
+    sp, p = tagged(nb, n, 23)
+    grp = LetGroup(nb, sp, p, world, 1e-4)
+    grp.step()
+    got = by_tag(nb, grp.particles())
+    want = oracle.naive_step_f64(nb.as_floats(p), sp.g, sp.e, sp.dt)
+    want = want[np.argsort(want[:, 9], kind="stable")]
+    scale = np.abs(want[:, 6:9]).max()
+    assert np.abs(got[:, 6:9] - want[:, 6:9]).max() <= 2e-5 * scale
+    assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 1e-6
+    grp.destroy()
+
+
+def test_let_force_error_is_that_of_the_single_tree(gpu, oracle):
+    """Against exact all-pairs forces the sum of per-domain walks is as good as one octree."""
+    nb = gpu
+    n, theta = 16384, 0.5
+    sp, p = tagged(nb, n, 24)
+    exact = oracle.naive_step_f64(nb.as_floats(p), sp.g, sp.e, sp.dt)
+    exact = exact[np.argsort(exact[:, 9], kind="stable")][:, 6:9]
+    single = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(theta), p)
+    single.encode()
+    one = by_tag(nb, single.dest_particle_slice())[:, 6:9]
+    single.destroy()
+    norm = np.linalg.norm(exact, axis=1)
+    err_one = np.median(np.linalg.norm(one - exact, axis=1) / norm)
+    for world in (2, 4, 8):
+        grp = LetGroup(nb, sp, p, world, theta)
+        grp.step()
+        let = by_tag(nb, grp.particles())[:, 6:9]
+        grp.destroy()
+        err_let = np.median(np.linalg.norm(let - exact, axis=1) / norm)
+        assert err_let <= 1.25 * err_one + 1e-6, (world, err_let, err_one)
+        assert np.median(np.linalg.norm(let - one, axis=1) / norm) <= 2.5 * err_one
+
+
+def test_let_export_capacity_is_checked(gpu):
+    nb = gpu
+    sp, p = tagged(nb, 4000, 25)
+    grp = LetGroup(nb, sp, p, 2, 0.3, cap=64)     # far too small for a neighbour's LET
+    grp.step()
+    with pytest.raises(nb.NBodyError) as ex:
+        for s in grp.sims:
+            s.dest_particle_slice()
+    assert "tree_let_cap" in str(ex.value)
+    grp.destroy()
+
+
+def test_let_phases_must_run_in_order(gpu):
+    nb = gpu
+    sp, p = tagged(nb, 512, 26)
+    s = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), p)
+    with pytest.raises(nb.NBodyError):
+        s.encode_phase(META)                      # LET not configured
+    s.set_tuning("tree_let_world", 2)
+    s.set_tuning("tree_let_rank", 0)
+    s.set_tuning("tree_let_cap", 4096)
+    with pytest.raises(nb.NBodyError):
+        s.encode_phase(BUILD)                     # META first
+    with pytest.raises(nb.NBodyError):
+        s.encode()                                # the plain step is not available in LET mode
+    s.encode_phase(META)
+    s.encode_phase(BUILD)
+    with pytest.raises(nb.NBodyError):
+        s.encode_phase(WALK)                      # imports not declared
+    s.let_set_imports([0, 0])
+    s.encode_phase(WALK)
+    s.wait()
+    s.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world):
+    """The product class (LetTreeSim: torch.distributed for the three exchanges) as `world`
+    processes on this one GPU, gloo standing in for RCCL == the in-process emulation above."""
+    import socket
+    import subprocess
+    import sys
+    nb = gpu
+    n, steps, theta = 6000, 3, 0.5
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
+             str(n), str(steps), "let"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    sp, p0 = tagged(nb, n, 27)
+    grp = LetGroup(nb, sp, p0, world, theta)
+    for _ in range(steps):
+        grp.step()
+    want = by_tag(nb, grp.particles())
+    grp.destroy()
+    got = np.concatenate([np.load(os.path.join(tmp_path, f"rank{r}.npy")) for r in range(world)])
+    got = got[np.argsort(got[:, 9], kind="stable")]
+    assert np.array_equal(bits(got), bits(want))

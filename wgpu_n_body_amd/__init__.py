@@ -227,6 +227,11 @@ class Simulator:
         """Half a step (nb_sim_encode_phase): 0 = own bodies' tiles, 1 = the rest + integrate."""
         check(_lib.lib().nb_sim_encode_phase(self._h, int(phase)))
 
+    def let_set_imports(self, counts) -> None:
+        """LET protocol (nb_sim_let_set_imports): records received from every rank this step."""
+        arr = (C.c_uint32 * len(counts))(*[int(c) for c in counts])
+        check(_lib.lib().nb_sim_let_set_imports(self._h, arr, len(counts)))
+
     # -- Simulator::cleanup --
     def cleanup(self) -> None:
         check(_lib.lib().nb_sim_cleanup(self._h))

@@ -445,6 +445,9 @@ int nb_sim_create_from_particles(nb_sim **out, const nb_sim_params *sim_params,
 
 int nb_sim_encode(nb_sim *sim) { NB_SIM_CALL(sim, encode()) }
 int nb_sim_encode_phase(nb_sim *sim, int phase) { NB_SIM_CALL(sim, encode_phase(phase)) }
+int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world) {
+    NB_SIM_CALL(sim, let_set_imports(counts, world))
+}
 int nb_sim_cleanup(nb_sim *sim) { NB_SIM_CALL(sim, cleanup()) }
 int nb_sim_wait(nb_sim *sim) { NB_SIM_CALL(sim, wait()) }
 

@@ -32,6 +32,10 @@ class SimBase {
         set_error("this simulator has no exchange region");
         return NB_ERR_UNSUPPORTED;
     }
+    virtual int let_set_imports(const uint32_t *, int) {
+        set_error("let_set_imports: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int read_tree(nb_octant *, size_t, size_t *, float *) {
         set_error("read_tree: not a TreeSim");
         return NB_ERR_UNSUPPORTED;

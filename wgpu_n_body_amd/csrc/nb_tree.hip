@@ -618,6 +618,14 @@ struct StackEntry {
 };
 constexpr uint32_t kWalkBatch = 4;  // records fetched together (a group is 1..8 cells)
 
+// The trees a wave walks: its own (record 0) and, on a multi-GPU run, the imported locally
+// essential trees of the peers (section 9).
+constexpr int kLetMaxWorld = 16;
+struct WalkRoots {
+    uint32_t count;
+    uint32_t id[kLetMaxWorld];
+};
+
 struct WalkStats {
     unsigned long long visits = 0, accepts = 0;
     uint32_t wave_cells = 0, wave_leaves = 0, max_sp = 1;
@@ -676,9 +684,9 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
-    const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
+    WalkRoots roots,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
-    uint32_t n, uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
+    uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -698,8 +706,6 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
     float ax = 0.f, ay = 0.f, az = 0.f;
-    (void)n_nodes_p;
-    (void)n_cap;
     const float theta2 = theta * theta;
     WalkStats st;
     const bool lane0 = lane == 0u;
@@ -707,9 +713,11 @@ __global__ __launch_bounds__(256) void walk_kernel(
     StackEntry *stack = s_stack[wave];
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
-    if (n >= 2 && all) {
-        if (lane0) stack[0] = StackEntry{0u, 1u, (uint32_t)all, (uint32_t)(all >> 32)};  // the root
-        sp = 1;
+    if (all) {  // the roots, pushed so that roots.id[0] is walked first
+        for (uint32_t k = roots.count; k > 0u; --k) {
+            if (lane0) stack[sp] = StackEntry{roots.id[k - 1u], 1u, (uint32_t)all, (uint32_t)(all >> 32)};
+            sp += 1;
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // Termination: a group's children have larger ids than their parent (fill_kernel enforces
@@ -757,6 +765,155 @@ __global__ __launch_bounds__(256) void walk_kernel(
         atomicAdd(&counters[0], st.visits);
         atomicAdd(&counters[1], st.accepts);
     }
+}
+
+// ---- 9. locally essential trees (multi-GPU Barnes-Hut) ------------------------
+// Every rank owns a Morton range of the bodies and builds the octree of ITS bodies inside the
+// GLOBAL root cube.  What a peer needs of that tree to walk it for its own bodies is the
+// "locally essential tree" (LET): starting at the root, a cell that EVERY point of the peer's
+// bounding box accepts (size^2 < theta^2 * dmin^2, dmin = distance from the cell's centre of
+// gravity to the box) is exported as a terminal pseudo-body, any other cell is exported with
+// its children.  dmin^2 is evaluated with the walk's own operation order on the per-axis
+// clamped distances, and fp32 subtract / multiply / fma are monotonic, so dmin^2 <= the r^2 any
+// body inside the box computes: the pruning never changes a decision a body of the peer would
+// take -- walking the LET gives bit for bit what walking the whole remote tree would give.
+//
+// Per-rank meta words exchanged before the build (all-gather): [0] bits of max |coord| of the
+// source positions (the global root cube is the max over ranks), [1..3] / [4..6] min / max of the
+// DRIFTED positions (the points the walk evaluates at) in an order-preserving u32 encoding.
+constexpr int kLetMetaWords = 8;
+
+__device__ __forceinline__ uint32_t let_f2ord(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float let_ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void let_meta_kernel(const float4 *__restrict__ posm,
+                                                       const float4 *__restrict__ vel,
+                                                       const float4 *__restrict__ acc, uint32_t n, float dt,
+                                                       uint32_t *__restrict__ meta) {
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = posm[i], v = vel[i], a = acc[i];
+        // exactly the walk's evaluation point (kick + drift, tree.wgsl:105-106)
+        const float x = drift(p.x, kick(v.x, a.x, dt), dt), y = drift(p.y, kick(v.y, a.y, dt), dt),
+                    z = drift(p.z, kick(v.z, a.z, dt), dt);
+        lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+        lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+        lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[threadIdx.x >> 6][c] = lo[c];
+            s_hi[threadIdx.x >> 6][c] = hi[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+        const float h = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+        if (l <= h) {  // (a block that saw no body contributes nothing)
+            atomicMin(&meta[1 + c], let_f2ord(l));
+            atomicMax(&meta[4 + c], let_f2ord(h));
+        }
+    }
+}
+
+// the global root cube: max over ranks of the local bounds (bit patterns of floats >= 1.0)
+__global__ void let_global_bound_kernel(const uint32_t *__restrict__ meta_all, int world,
+                                        uint32_t *__restrict__ bound_bits) {
+    uint32_t m = __float_as_uint(1.0f);
+    for (int r = 0; r < world; ++r) m = max(m, meta_all[r * kLetMetaWords]);
+    *bound_bits = m;
+}
+
+// One depth of the export, all peers at once (blockIdx.y = peer).  Node ids are breadth-first
+// (depth-major), so the nodes of one depth are a contiguous id range and their parents were
+// handled by the previous launch: a reached node finds its output slot in out_slot.
+__global__ __launch_bounds__(256) void let_export_level_kernel(
+    const NodeRec *__restrict__ rec, const uint32_t *__restrict__ depth_base, int depth,
+    const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, const uint32_t *__restrict__ meta_all,
+    int rank, float theta2, bool prune, uint32_t *__restrict__ out_slot, NodeRec *__restrict__ send,
+    uint32_t *__restrict__ counts, uint32_t cap, uint32_t *__restrict__ status) {
+    const int q = blockIdx.y;
+    if (q == rank) return;
+    const uint32_t n_nodes = min(*n_nodes_p, n_cap);
+    const uint32_t begin = depth_base[depth], end = min(depth_base[depth + 1], n_nodes);
+    if (begin >= end) return;
+    const uint32_t *mq = meta_all + q * kLetMetaWords;
+    const float blo[3] = {let_ord2f(mq[1]), let_ord2f(mq[2]), let_ord2f(mq[3])};
+    const float bhi[3] = {let_ord2f(mq[4]), let_ord2f(mq[5]), let_ord2f(mq[6])};
+    if (!(blo[0] <= bhi[0])) return;  // the peer has no bodies: nothing to export
+    uint32_t *slots = out_slot + (size_t)q * n_cap;
+    NodeRec *out = send + (size_t)q * cap;
+    for (uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x; id < end;
+         id += gridDim.x * blockDim.x) {
+        const uint32_t slot = depth == 0 ? 0u : slots[id];
+        if (slot >= cap) continue;  // ~0: not reached for this peer
+        const NodeRec r = rec[id];
+        NodeRec o{r.cogm, 0u, 0u, ~0u, -1.0f};  // terminal: a body / pseudo-body for the peer
+        if (r.count != 0u) {
+            // nearest point of the box to the centre of gravity, per axis, then r^2 in the walk's order
+            const float dx = r.cogm.x - fminf(fmaxf(r.cogm.x, blo[0]), bhi[0]);
+            const float dy = r.cogm.y - fminf(fmaxf(r.cogm.y, blo[1]), bhi[1]);
+            const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
+            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (!prune || !(r.ssize2 < theta2 * r2)) {  // some point of the box may open it: export the children
+                const uint32_t base = atomicAdd(&counts[q], r.count);
+                if (base + r.count <= cap && r.first + r.count <= n_nodes) {
+                    for (uint32_t c = 0; c < r.count; ++c) slots[r.first + c] = base + c;
+                    o = NodeRec{r.cogm, base, r.count, ~0u, r.ssize2};
+                } else {
+                    atomicAdd(&status[0], 1u);  // capacity exceeded: reported by check_status
+                }
+            }
+        }
+        out[slot] = o;
+    }
+}
+
+// a peer whose export ran out of room (status[0], an error at the next read-back) still gets a
+// count that fits its segment
+__global__ void let_clamp_counts_kernel(uint32_t *__restrict__ counts, int world, uint32_t cap) {
+    const int q = threadIdx.x;
+    if (q < world) counts[q] = min(counts[q], cap);
+}
+
+struct LetSegments {
+    uint32_t world;
+    uint32_t off[kLetMaxWorld + 1];  // record offsets of the imported segments (exclusive scan)
+};
+
+// imported child links are relative to their segment: make them indices into the walk's table,
+// and turn any link that does not point forward inside its own segment into a terminal
+__global__ void let_rebase_kernel(NodeRec *__restrict__ imp, LetSegments segs, uint32_t import_base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= segs.off[segs.world]) return;
+    uint32_t s = 0;
+    while (s + 1 < segs.world && i >= segs.off[s + 1]) ++s;
+    NodeRec r = imp[i];
+    const uint32_t local = i - segs.off[s], seg_n = segs.off[s + 1] - segs.off[s];
+    r.self_pos = ~0u;
+    if (r.count != 0u) {
+        if (r.count <= 8u && r.first > local && r.first + r.count <= seg_n) {
+            r.first += import_base + segs.off[s];
+        } else {
+            r.first = 0u;
+            r.count = 0u;
+            r.ssize2 = -1.0f;
+        }
+    }
+    imp[i] = r;
 }
 
 // ---- AoS conversion of the device tree (nb_sim_read_tree) ---------------------------------------
@@ -915,8 +1072,14 @@ class TreeSim final : public SimBase {
     // the position all-gather of the previous step has landed and lets the other two overlap it.
     int encode_phase(int phase) override {
         if (int rc = bind_device()) return rc;
+        if (phase >= NB_PHASE_LET_META && phase <= NB_PHASE_LET_WALK) return let_phase(phase);
         if (phase != 0 && phase != 1) {
-            set_error("encode_phase: phase must be 0 or 1");
+            set_error("encode_phase: phase must be 0 or 1 (or a NB_PHASE_LET_* value)");
+            return NB_ERR_INVALID;
+        }
+        if (let_world) {
+            set_error("encode_phase(%d): this TreeSim runs the LET protocol (phases %d..%d)", phase,
+                      NB_PHASE_LET_META, NB_PHASE_LET_WALK);
             return NB_ERR_INVALID;
         }
         if (n == 0) {
@@ -928,26 +1091,170 @@ class TreeSim final : public SimBase {
                 set_error("encode_phase(0) called twice for one step");
                 return NB_ERR_INVALID;
             }
-            if (int rc = enqueue_build()) return rc;
+            if (int rc = enqueue_build(false)) return rc;
             build_done = true;
             return NB_OK;
         }
         if (!build_done)
-            if (int rc = enqueue_build()) return rc;
+            if (int rc = enqueue_build(false)) return rc;
         build_done = false;
-        if (int rc = enqueue_walk()) return rc;
+        if (int rc = enqueue_walk(own_root())) return rc;
         step_num += 1;
         return NB_OK;
     }
 
-    int enqueue_step() {
-        if (!build_done)
-            if (int rc = enqueue_build()) return rc;
-        build_done = false;
-        return enqueue_walk();
+    WalkRoots own_root() const {
+        WalkRoots r{};
+        r.count = n >= 2 ? 1u : 0u;  // (the reference's N = 1 tree is ill-formed; a lone body feels nothing)
+        return r;
     }
 
-    int enqueue_build() {
+    // ---- locally essential trees: the three phases of a multi-GPU step (see section 9) -----------
+    // NB_PHASE_LET_META   local bound + drifted bounding box -> this rank's meta words
+    //                     (caller: all-gather exchange region 0)
+    // NB_PHASE_LET_BUILD  global root cube, local octree, LET export for every peer
+    //                     (caller: all-gather region 1 = export counts, read them on the host,
+    //                      all-to-all the segments of region 2 into region 3, nb_sim_let_set_imports)
+    // NB_PHASE_LET_WALK   rebase the imported trees, walk own tree + imports, integrate
+    int let_phase(int phase) {
+        if (!let_world || !let_send) {
+            set_error("LET phase %d: set tree_let_world, tree_let_rank and tree_let_cap first", phase);
+            return NB_ERR_INVALID;
+        }
+        if (phase != let_next) {
+            set_error("LET phases must run in order: expected %d, got %d", let_next, phase);
+            return NB_ERR_INVALID;
+        }
+        const int s = cur;
+        const dim3 b256(256);
+        uint32_t *my_meta = let_meta + (size_t)let_rank * kLetMetaWords;
+        uint32_t *n_nodes = scalars + 1, *status = scalars + 4, *depth_base = scalars + 16;
+        if (phase == NB_PHASE_LET_META) {
+            const uint32_t init_meta[kLetMetaWords] = {0u, ~0u, ~0u, ~0u, 0u, 0u, 0u, 0u};
+            NB_HIP_TRY(hipMemcpyAsync(my_meta, init_meta, sizeof init_meta, hipMemcpyHostToDevice, stream));
+            if (n) {
+                const uint32_t g = std::min<uint32_t>((n + 255) / 256, 512);
+                hipLaunchKernelGGL(bound_kernel, dim3(g), b256, 0, stream, posm[s], n, my_meta);
+                hipLaunchKernelGGL(let_meta_kernel, dim3(g), b256, 0, stream, posm[s], vel[s], acc[s], n,
+                                   params.dt, my_meta);
+            }
+            NB_HIP_TRY(hipGetLastError());
+            let_next = NB_PHASE_LET_BUILD;
+            return NB_OK;
+        }
+        if (phase == NB_PHASE_LET_BUILD) {
+            uint32_t *my_counts = let_counts + (size_t)let_rank * let_world;
+            NB_HIP_TRY(hipMemsetAsync(my_counts, 0, sizeof(uint32_t) * let_world, stream));
+            if (n) {
+                NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));
+                hipLaunchKernelGGL(let_global_bound_kernel, dim3(1), dim3(1), 0, stream, let_meta, let_world,
+                                   scalars + 0);
+                if (int rc = enqueue_build(true)) return rc;
+                // every peer's export starts with the root in slot 0
+                std::vector<uint32_t> ones(let_world, 1u);
+                ones[let_rank] = 0u;
+                NB_HIP_TRY(hipMemcpyAsync(my_counts, ones.data(), sizeof(uint32_t) * let_world,
+                                          hipMemcpyHostToDevice, stream));
+                NB_HIP_TRY(hipMemsetAsync(let_out_slot, 0xff, sizeof(uint32_t) * (size_t)let_world * node_cap,
+                                          stream));
+                for (int d = 0; d <= kMaxDepth; ++d)
+                    hipLaunchKernelGGL(let_export_level_kernel, dim3(128, let_world), b256, 0, stream, rec,
+                                       depth_base, d, n_nodes, node_cap, let_meta, let_rank, theta * theta,
+                                       let_prune, let_out_slot, let_send, my_counts, let_cap, status);
+                hipLaunchKernelGGL(let_clamp_counts_kernel, dim3(1), dim3(64), 0, stream, my_counts, let_world,
+                                   let_cap);
+                NB_HIP_TRY(hipGetLastError());
+            }
+            let_next = NB_PHASE_LET_WALK;
+            let_imports_set = false;
+            return NB_OK;
+        }
+        // NB_PHASE_LET_WALK
+        if (!let_imports_set) {
+            set_error("LET walk: call nb_sim_let_set_imports with this step's import counts first");
+            return NB_ERR_INVALID;
+        }
+        WalkRoots roots{};
+        if (n) roots.id[roots.count++] = 0u;
+        const uint32_t total = let_segs.off[let_segs.world];
+        if (total) {
+            hipLaunchKernelGGL(let_rebase_kernel, dim3((total + 255) / 256), b256, 0, stream, rec + node_cap,
+                               let_segs, node_cap);
+            for (uint32_t r = 0; r < let_segs.world; ++r)
+                if (let_segs.off[r + 1] > let_segs.off[r]) roots.id[roots.count++] = node_cap + let_segs.off[r];
+        }
+        if (n) {
+            if (int rc = enqueue_walk(roots)) return rc;
+        }
+        step_num += 1;
+        let_next = NB_PHASE_LET_META;
+        return NB_OK;
+    }
+
+    int let_set_imports(const uint32_t *counts, int world) override {
+        if (!let_world || world != let_world || !counts) {
+            set_error("let_set_imports: world %d does not match tree_let_world %d", world, let_world);
+            return NB_ERR_INVALID;
+        }
+        uint64_t run = 0;
+        let_segs.world = (uint32_t)world;
+        for (int r = 0; r < world; ++r) {
+            let_segs.off[r] = (uint32_t)run;
+            run += (r == let_rank) ? 0u : counts[r];
+            if (counts[r] > let_cap) {
+                set_error("let_set_imports: %u records from rank %d exceed the capacity %u", counts[r], r, let_cap);
+                return NB_ERR_INVALID;
+            }
+        }
+        let_segs.off[world] = (uint32_t)run;
+        let_imports_set = true;
+        return NB_OK;
+    }
+
+    int let_setup(uint32_t cap) {
+        if (let_world < 1 || let_world > kLetMaxWorld || let_rank < 0 || let_rank >= let_world) {
+            set_error("LET: world %d / rank %d out of range (at most %d ranks)", let_world, let_rank, kLetMaxWorld);
+            return NB_ERR_INVALID;
+        }
+        if (place.world != 1) {
+            set_error("LET: create the TreeSim over the rank's own bodies (placement world 1)");
+            return NB_ERR_INVALID;
+        }
+        if (let_send) {
+            set_error("LET buffers are already allocated");
+            return NB_ERR_INVALID;
+        }
+        if (int rc = bind_device()) return rc;
+        let_cap = cap;
+        const size_t w = (size_t)let_world;
+        if (int rc = alloc(&let_meta, sizeof(uint32_t) * kLetMetaWords * w)) return rc;
+        if (int rc = alloc(&let_counts, sizeof(uint32_t) * w * w)) return rc;
+        if (int rc = alloc(&let_out_slot, sizeof(uint32_t) * w * (size_t)node_cap)) return rc;
+        if (int rc = alloc(&let_send, sizeof(NodeRec) * w * (size_t)cap)) return rc;
+        // the walk addresses own and imported records through one table: own tree first, imports after
+        NodeRec *table = nullptr;
+        if (int rc = alloc(&table, sizeof(NodeRec) * ((size_t)node_cap + w * (size_t)cap + 4))) return rc;
+        rec = table;
+        NB_HIP_TRY(hipMemsetAsync(let_meta, 0, sizeof(uint32_t) * kLetMetaWords * w, stream));
+        NB_HIP_TRY(hipMemsetAsync(let_counts, 0, sizeof(uint32_t) * w * w, stream));
+        NB_HIP_TRY(hipStreamSynchronize(stream));
+        let_next = NB_PHASE_LET_META;
+        return NB_OK;
+    }
+
+    int enqueue_step() {
+        if (let_world) {
+            set_error("this TreeSim runs the LET protocol: use nb_sim_encode_phase(NB_PHASE_LET_*)");
+            return NB_ERR_INVALID;
+        }
+        if (!build_done)
+            if (int rc = enqueue_build(false)) return rc;
+        build_done = false;
+        return enqueue_walk(own_root());
+    }
+
+    // external_bound: the root cube is already in scalars[0] (LET: the max over all ranks)
+    int enqueue_build(bool external_bound) {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
         uint32_t *zero_word = scalars + 8;    // stays 0
@@ -955,9 +1262,11 @@ class TreeSim final : public SimBase {
         const dim3 b256(256);
         const uint32_t g256 = (n + 255) / 256;
         // 1-2: bound + keys from the step's source positions (old positions, tree.rs:290-295)
-        NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));  // status words are sticky
-        hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
-                           bound_bits);
+        if (!external_bound) {
+            NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));  // status words are sticky
+            hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
+                               bound_bits);
+        }
         hipLaunchKernelGGL(morton_kernel, dim3(g256), b256, 0, stream, posm[s], n, bound_bits, keys[0],
                            idx[0]);
         // 3: sort (key, index) by key
@@ -1004,9 +1313,9 @@ class TreeSim final : public SimBase {
         return NB_OK;
     }
 
-    int enqueue_walk() {
+    int enqueue_walk(const WalkRoots &roots) {
         const int s = cur, d = cur ^ 1;
-        uint32_t *n_nodes = scalars + 1, *status = scalars + 4;
+        uint32_t *status = scalars + 4;
         const dim3 b256(256);
         hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
                            vel[d], acc[d]);
@@ -1016,11 +1325,11 @@ class TreeSim final : public SimBase {
             const dim3 gwalk((hi - lo + 255) / 256);
             if (count_visits)
                 hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   roots, posm[s], vel[s], acc[s], lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
             else
                 hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   n_nodes, node_cap, posm[s], vel[s], acc[s], n, lo, hi,
+                                   roots, posm[s], vel[s], acc[s], lo, hi,
                                    params.g, params.e, params.dt, theta, status, counters);
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
@@ -1046,12 +1355,13 @@ class TreeSim final : public SimBase {
         uint32_t st[4] = {0, 0, 0, 0};
         NB_HIP_TRY(hipMemcpy(st, scalars + 4, sizeof st, hipMemcpyDeviceToHost));
         if (st[0]) {
-            set_error("tree walk stack overflowed %u times (more than %u pending cells per wave)", st[0],
-                      kWalkStack);
+            set_error("LET export needs more than tree_let_cap = %u records for a peer (%u cells cut short)",
+                      let_cap, st[0]);
             return NB_ERR_UNSUPPORTED;
         }
         if (st[3]) {
-            set_error("tree walk exceeded its node budget %u times (inconsistent tree)", st[3]);
+            set_error("tree walk hit its stack guard %u times (more than %u pending groups per wave: "
+                      "inconsistent tree)", st[3], kWalkStack - 8);
             return NB_ERR_UNSUPPORTED;
         }
         if (st[1]) {
@@ -1121,8 +1431,32 @@ class TreeSim final : public SimBase {
 
     // Sharded TreeSim = replicated tree, partitioned walk: after encode the
     // rank's range of the three state arrays is new; the caller all-gathers each in place.
-    int exchange_count() override { return 3; }
+    // In LET mode the regions are the protocol's four buffers: 0 meta words (all-gather, 32 B per
+    // rank), 1 export counts (all-gather, one row of `world` u32 per rank), 2 the export segments
+    // (segment q = records for peer q, stride = slice_bytes), 3 the import area (packed by the
+    // caller in rank order, skipping itself).
+    int exchange_count() override { return let_world ? 4 : 3; }
     int exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) override {
+        if (let_world) {
+            if (index < 0 || index > 3 || !let_send) {
+                set_error("LET exchange region %d out of range (4 regions, after tree_let_cap is set)", index);
+                return NB_ERR_INVALID;
+            }
+            const size_t w = (size_t)let_world;
+            void *base = nullptr;
+            size_t o = 0, l = 0, t = 0;
+            switch (index) {
+            case 0: base = let_meta; l = sizeof(uint32_t) * kLetMetaWords; o = l * let_rank; t = l * w; break;
+            case 1: base = let_counts; l = sizeof(uint32_t) * w; o = l * let_rank; t = l * w; break;
+            case 2: base = let_send; l = sizeof(NodeRec) * (size_t)let_cap; t = l * w; break;
+            default: base = rec + node_cap; l = sizeof(NodeRec) * (size_t)let_cap; t = l * w; break;
+            }
+            if (dev_ptr) *dev_ptr = base;
+            if (off) *off = o;
+            if (len) *len = l;
+            if (total) *total = t;
+            return NB_OK;
+        }
         if (index < 0 || index > 2) {
             set_error("exchange region %d out of range (TreeSim has 3)", index);
             return NB_ERR_INVALID;
@@ -1145,6 +1479,25 @@ class TreeSim final : public SimBase {
             use_graph = value != 0;
             drop_graph();
             return NB_OK;
+        }
+        if (std::strcmp(key, "tree_let_world") == 0) {
+            let_world = value;
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_let_rank") == 0) {
+            let_rank = value;
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_let_prune") == 0) {  // 0: export whole trees (testing: same result)
+            let_prune = value != 0;
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_let_cap") == 0) {  // records per peer; allocates the LET buffers
+            if (value <= 0) {
+                set_error("tree_let_cap must be positive");
+                return NB_ERR_INVALID;
+            }
+            return let_setup((uint32_t)value);
         }
         return SimBase::set_tuning(key, value);
     }
@@ -1199,6 +1552,13 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false, use_graph = false;
     bool build_done = false;  // phase 0 of the next step already enqueued
+    // locally essential trees (section 9); let_world == 0: not in use
+    int let_world = 0, let_rank = 0, let_next = 0;
+    uint32_t let_cap = 0;
+    uint32_t *let_meta = nullptr, *let_counts = nullptr, *let_out_slot = nullptr;
+    NodeRec *let_send = nullptr;
+    LetSegments let_segs{};
+    bool let_imports_set = false, let_prune = true;
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;

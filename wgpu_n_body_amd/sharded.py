@@ -21,7 +21,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import (AddParams, NaiveSim, Placement, SimParams, TreeSim, as_particles,
+from . import (AddParams, NaiveSim, Placement, SimParams, TreeSim, as_floats, as_particles,
                shard_bodies_per_rank)
 
 
@@ -267,3 +267,183 @@ class ShardedTreeSim:
         self.wait()
         self._views.clear()
         self.sim.destroy()
+
+
+def morton_order(particles: np.ndarray) -> np.ndarray:
+    """Indices that sort bodies along a Morton (Z-order) curve of their positions -- used only to
+    hand every rank a compact spatial domain at start-up (any space-filling order would do; the
+    octree itself is keyed on the device by the reference's own descent)."""
+    f = as_floats(particles)
+    pos = f[:, 0:3].astype(np.float64)
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    span = np.maximum(hi - lo, 1e-30)
+    q = np.minimum(((pos - lo) / span * 2097152.0).astype(np.uint64), np.uint64(2097151))  # 21 bits/axis
+
+    def spread(v):  # insert two zero bits after each of the 21 low bits
+        v = v & np.uint64(0x1fffff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(key, kind="stable")
+
+
+class LetTreeSim:
+    """Barnes-Hut on several GPUs, SURVEY 8(e) step 2: Morton-range domains, local octrees and a
+    locally-essential-tree (LET) exchange (nb_sim_encode_phase(NB_PHASE_LET_*), include/nbody.h).
+
+    Start-up: the bodies are ordered along a Morton curve and cut into `world` equal runs; rank r
+    keeps run r for good (velocities and accelerations never leave their owner).  Per step:
+      1. NB_PHASE_LET_META  -> all-gather 32 B per rank (local bound, box of the drifted bodies);
+      2. NB_PHASE_LET_BUILD -> every rank builds the octree of ITS bodies inside the global root
+         cube and prunes it against each peer's box; all-gather the `world` export counts, read
+         them on the host (the one host synchronisation of the step), all-to-all the segments;
+      3. NB_PHASE_LET_WALK  -> walk own tree + the imported trees, integrate.
+    What a body feels is the sum of per-domain Barnes-Hut walks (each with the reference's
+    per-body acceptance test); the pruning is decision-exact, so the result does not depend on
+    the peers' boxes or on the exchange -- only on which bodies share a domain.
+
+    Bodies are not migrated: a domain is "the bodies a rank started with", its box follows them.
+    `rebalance()` (collective) re-cuts the domains from the current positions."""
+
+    META, BUILD, WALK = 2, 3, 4
+
+    def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
+                 device_index: int, group=None, let_cap: Optional[int] = None):
+        import torch
+        self._torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        self.theta = float(theta)
+        self.params = sim_params
+        self._dev = torch.device("cuda", device_index)
+        self._device_index = device_index
+        self.stream = torch.cuda.Stream(self._dev)
+        self.sim = None
+        self.step_num = 0
+        self._let_cap = let_cap
+        self._adopt(as_particles(particles))
+
+    # -- domain set-up -------------------------------------------------------------------------
+    def _adopt(self, particles: np.ndarray) -> None:
+        order = morton_order(particles)
+        cuts = [(len(order) * r) // self.world for r in range(self.world + 1)]
+        self.counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+        mine = np.ascontiguousarray(particles[order[cuts[self.rank]:cuts[self.rank + 1]]])
+        if self.sim is not None:
+            self.sim.destroy()
+        sp = SimParams(particle_num=len(mine), g=self.params.g, e=self.params.e, dt=self.params.dt)
+        self.sim = TreeSim.from_particles(sp, AddParams.TreeSimParams(self.theta), mine,
+                                          Placement(self._device_index, 0, 1, self.stream.cuda_stream))
+        # a peer can need at most this rank's whole octree (< 2 n_local + 1 nodes for distinct
+        # bodies); default to that, capped to keep 2 x world x cap x 32 B reasonable
+        cap = self._let_cap or max(4096, 2 * max(self.counts) + 64)
+        self.sim.set_tuning("tree_let_world", self.world)
+        self.sim.set_tuning("tree_let_rank", self.rank)
+        self.sim.set_tuning("tree_let_cap", int(cap))
+        self.cap = int(cap)
+        t = self._torch
+        self._views = []
+        for k in range(4):
+            ptr, off, ln, tot = self.sim.exchange_region(k)
+            self._views.append((t.as_tensor(_DevicePtr(ptr, tot // 4), device=self._dev), off // 4, ln // 4))
+        self._pinned_counts = t.empty(self.world * self.world, dtype=t.int32).pin_memory() \
+            if t.cuda.is_available() else None
+
+    # -- one step --------------------------------------------------------------------------------
+    def _all_gather(self, k: int) -> None:
+        import torch.distributed as dist
+        full, off, ln = self._views[k]
+        if self.world > 1:
+            dist.all_gather_into_tensor(full, full[off:off + ln], group=self.group)
+
+    def _exchange_segments(self, counts: np.ndarray) -> list:
+        """Move counts[r][me] records of rank r's segment `me` into the import area, packed in
+        rank order.  RCCL: one grouped all-to-all on device views.  Other backends (the gloo
+        rehearsal): point-to-point through host memory."""
+        import torch.distributed as dist
+        t = self._torch
+        send, _, seg = self._views[2]
+        recv, _, _ = self._views[3]
+        me, W, R = self.rank, self.world, 8          # R = floats per 32-byte record
+        recv_counts = [0 if r == me else int(counts[r, me]) for r in range(W)]
+        send_counts = [0 if q == me else int(counts[me, q]) for q in range(W)]
+        offs = np.concatenate([[0], np.cumsum(recv_counts)])
+        outs = [recv[offs[r] * R:(offs[r] + recv_counts[r]) * R] for r in range(W)]
+        ins = [send[q * seg:q * seg + send_counts[q] * R] for q in range(W)]
+        if W == 1:
+            return recv_counts
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_to_all(outs, ins, group=self.group)
+            return recv_counts
+        self.stream.synchronize()
+        host_in = [x.cpu() for x in ins]
+        host_out = [t.empty(recv_counts[r] * R, dtype=t.float32) for r in range(W)]
+        ops = []
+        for peer in range(W):
+            if peer == me:
+                continue
+            if send_counts[peer]:
+                ops.append(dist.P2POp(dist.isend, host_in[peer], peer, group=self.group))
+            if recv_counts[peer]:
+                ops.append(dist.P2POp(dist.irecv, host_out[peer], peer, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for r in range(W):
+            if recv_counts[r]:
+                outs[r].copy_(host_out[r])
+        return recv_counts
+
+    def encode(self) -> None:
+        t = self._torch
+        with t.cuda.stream(self.stream):
+            self.sim.encode_phase(self.META)
+            self._all_gather(0)
+            self.sim.encode_phase(self.BUILD)
+            self._all_gather(1)
+            counts_dev = self._views[1][0].view(t.int32)
+            counts = counts_dev.cpu().numpy().astype(np.int64).reshape(self.world, self.world)
+            recv_counts = self._exchange_segments(counts)
+            self.last_counts = counts
+            self.sim.let_set_imports(recv_counts)
+            self.sim.encode_phase(self.WALK)
+        self.step_num += 1
+
+    def cleanup(self) -> None:
+        self.sim.cleanup()
+
+    def wait(self) -> None:
+        self.stream.synchronize()
+
+    # -- read-out ----------------------------------------------------------------------------------
+    def read_local(self) -> np.ndarray:
+        """This rank's bodies (post-step), in the rank's current sorted order."""
+        self.wait()
+        return self.sim.dest_particle_slice()
+
+    def read_particles(self) -> np.ndarray:
+        """All bodies, rank by rank (collective).  The order is not the input order: like the
+        reference's TreeSim, every step leaves the bodies in tree order."""
+        import torch.distributed as dist
+        mine = self.read_local()
+        if self.world == 1:
+            return mine
+        out = [None] * self.world
+        dist.all_gather_object(out, mine.tobytes(), group=self.group)
+        return np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in out])
+
+    def rebalance(self) -> None:
+        """Re-cut the domains from the current positions (collective, host-side: gathers all
+        bodies, re-orders them along the Morton curve and re-creates the local simulator)."""
+        self._adopt(self.read_particles().copy())
+
+    def destroy(self) -> None:
+        self.wait()
+        self._views = []
+        if self.sim is not None:
+            self.sim.destroy()
+            self.sim = None
