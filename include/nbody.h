@@ -211,6 +211,20 @@ int nb_sim_encode_phase(nb_sim *sim, int phase);
 #define NB_PHASE_LET_WALK 4
 int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world);
 
+/* Migration between LET steps.  A TreeSim created with more bodies than it starts with (the
+ * surplus is headroom; tuning key "tree_let_active" = bodies in use) can hand over the bodies
+ * that left its domain: rank r owns the Morton keys [splits[r-1], splits[r]) of positions
+ * quantised to 21 bits per axis in the fixed cube [-ref_bound, ref_bound]^3 (splits: world-1
+ * values).  NB_PHASE_LET_MIGRATE compacts the stayers and packs the leavers per owner (region 5,
+ * 48 B per body, at most seg_cap per owner) with the counts in region 4 (stayers at [rank]); the
+ * caller all-gathers region 4, moves the segments into region 6 packed in rank order and calls
+ * nb_sim_let_set_arrivals(stayers, arrivals per rank); nb_sim_sim_params then reports the new
+ * body count. */
+#define NB_PHASE_LET_MIGRATE 5
+int nb_sim_let_set_owners(nb_sim *sim, const unsigned long long *splits, int world, float ref_bound,
+                          uint32_t seg_cap);
+int nb_sim_let_set_arrivals(nb_sim *sim, uint32_t stay, const uint32_t *counts, int world);
+
 /* `Simulator::cleanup(&mut self)`, src/sims/mod.rs:87-89 (TreeSim resets its
  * arena, src/sims/tree.rs:363-365).  Host-side housekeeping that may overlap
  * the enqueued step.  No-op for the all-pairs simulator. */

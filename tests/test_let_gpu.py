@@ -20,7 +20,7 @@ from tests.helpers import ROOT, bits
 
 pytestmark = pytest.mark.gpu
 
-META, BUILD, WALK = 2, 3, 4
+META, BUILD, WALK, MIGRATE = 2, 3, 4, 5
 REC = 32  # bytes per exported record
 
 
@@ -53,23 +53,30 @@ def by_tag(nb, particles):
 class LetGroup:
     """`world` TreeSims on one GPU running the LET protocol, exchanges by hipMemcpy."""
 
-    def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None):
-        from wgpu_n_body_amd.sharded import morton_order
+    def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0):
+        from wgpu_n_body_amd.sharded import morton_domains
         self.nb, self.world, self.hip = nb, world, _hip()
-        order = morton_order(particles)
-        cuts = [(len(order) * r) // world for r in range(world + 1)]
+        self.migrate_every, self.steps_done = migrate_every, 0
+        order, cuts, splits, ref_bound = morton_domains(particles, world, with_owners=True)
+        counts = [cuts[r + 1] - cuts[r] for r in range(world)]
+        capacity = int(1.25 * max(counts)) + 4096
+        self.mig_cap = max(1024, capacity // 8)
         self.sims = []
         for r in range(world):
-            mine = np.ascontiguousarray(particles[order[cuts[r]:cuts[r + 1]]])
-            spl = nb.SimParams(particle_num=len(mine), g=sp.g, e=sp.e, dt=sp.dt)
-            s = nb.TreeSim.from_particles(spl, nb.AddParams.TreeSimParams(theta), mine)
+            mine = particles[order[cuts[r]:cuts[r + 1]]]
+            padded = np.zeros(capacity, dtype=mine.dtype)
+            padded[:len(mine)] = mine
+            spl = nb.SimParams(particle_num=capacity, g=sp.g, e=sp.e, dt=sp.dt)
+            s = nb.TreeSim.from_particles(spl, nb.AddParams.TreeSimParams(theta), padded)
             s.set_tuning("tree_let_world", world)
             s.set_tuning("tree_let_rank", r)
+            s.set_tuning("tree_let_active", len(mine))
             s.set_tuning("tree_let_prune", 1 if prune else 0)
-            s.set_tuning("tree_let_cap", cap or (2 * len(mine) + 64))
+            s.set_tuning("tree_let_cap", cap or (2 * capacity + 64))
+            s.let_set_owners(splits, ref_bound, self.mig_cap)
             self.sims.append(s)
-        self.cap = [cap or (2 * (cuts[r + 1] - cuts[r]) + 64) for r in range(world)]
         self.counts = None
+        self.migrated = 0
 
     def _copy(self, dst, src, nbytes):
         if nbytes:
@@ -85,34 +92,58 @@ class LetGroup:
                 if dst != src:
                     self._copy(dp_ + off, sp_ + off, ln)
 
-    def step(self):
+    def _matrix(self, k):
+        """all-gather region k, then the counts matrix as rank 0's host reads it"""
         W = self.world
+        self._all_gather(k)
+        ptr, _o, _l, tot = self.sims[0].exchange_region(k)
+        host = np.zeros(W * W, dtype=np.uint32)
+        assert self.hip.hipMemcpy(host.ctypes.data, ptr, tot, 2) == 0
+        return host.reshape(W, W).astype(np.int64)
+
+    def _all_to_all(self, counts, k_send, k_recv, rec_bytes):
+        """segment `me` of every peer's region k_send -> region k_recv of `me`, packed in rank order"""
+        W = self.world
+        received = []
+        for me, s in enumerate(self.sims):
+            rptr = s.exchange_region(k_recv)[0]
+            offs, recv = 0, []
+            for r in range(W):
+                c = 0 if r == me else int(counts[r, me])
+                recv.append(c)
+                if c:
+                    sptr, _o, seg, _t = self.sims[r].exchange_region(k_send)
+                    self._copy(rptr + offs * rec_bytes, sptr + me * seg, c * rec_bytes)
+                offs += c
+            received.append(recv)
+        return received
+
+    def migrate(self):
+        for s in self.sims:
+            s.encode_phase(MIGRATE)
+        counts = self._matrix(4)
+        received = self._all_to_all(counts, 5, 6, 48)
+        for me, s in enumerate(self.sims):
+            s.let_set_arrivals(int(counts[me, me]), received[me])
+        self.migrated += int(counts.sum() - np.trace(counts))
+        return counts
+
+    def step(self):
+        if self.migrate_every and self.steps_done and self.steps_done % self.migrate_every == 0:
+            self.migrate()
         for s in self.sims:
             s.encode_phase(META)
         self._all_gather(0)
         for s in self.sims:
             s.encode_phase(BUILD)
-        self._all_gather(1)
-        # the counts matrix, read on the "host" of rank 0 (identical everywhere after the gather)
-        ptr, _o, _l, tot = self.sims[0].exchange_region(1)
-        host = np.zeros(W * W, dtype=np.uint32)
-        assert self.hip.hipMemcpy(host.ctypes.data, ptr, tot, 2) == 0
-        counts = host.reshape(W, W).astype(np.int64)
+        counts = self._matrix(1)
         self.counts = counts
-        for me, s in enumerate(self.sims):          # all-to-all: segment `me` of every peer
-            rptr = s.exchange_region(3)[0]
-            offs = 0
-            recv = []
-            for r in range(W):
-                c = 0 if r == me else int(counts[r, me])
-                recv.append(c)
-                if c:
-                    sptr, _o, seg, _t = self.sims[r].exchange_region(2)
-                    self._copy(rptr + offs * REC, sptr + me * seg, c * REC)
-                offs += c
-            s.let_set_imports(recv)
+        received = self._all_to_all(counts, 2, 3, REC)
+        for me, s in enumerate(self.sims):
+            s.let_set_imports(received[me])
         for s in self.sims:
             s.encode_phase(WALK)
+        self.steps_done += 1
 
     def particles(self):
         return np.concatenate([s.dest_particle_slice() for s in self.sims])
@@ -232,6 +263,57 @@ def test_let_phases_must_run_in_order(gpu):
     s.destroy()
 
 
+def moving(nb, n, seed, speed):
+    """tagged() bodies with random velocities, so that some cross domain borders in a few steps"""
+    sp, p = tagged(nb, n, seed)
+    f = nb.as_floats(p)
+    rng = np.random.default_rng(seed)
+    f[:, 3:6] = rng.uniform(-speed, speed, size=(n, 3)).astype(np.float32)
+    return sp, p
+
+
+def test_let_migration_rehomes_bodies_and_stays_exact(gpu, oracle):
+    """With theta -> 0 the LET step is all-pairs whatever the domains are, so a run in which
+    bodies change owner every step must still track the fp64 all-pairs oracle."""
+    nb = gpu
+    n, world, steps = 3000, 4, 5
+    sp, p = moving(nb, n, 31, 1.5)
+    grp = LetGroup(nb, sp, p, world, 1e-4, migrate_every=1)
+    for _ in range(steps):
+        grp.step()
+    assert grp.migrated > 20                         # bodies did change owner
+    got = by_tag(nb, grp.particles())
+    assert len(got) == n and np.array_equal(got[:, 9], np.sort(nb.as_floats(p)[:, 9]))   # nobody lost
+    want = oracle.naive_run_f64(nb.as_floats(p), sp.g, sp.e, sp.dt, steps)
+    want = want[np.argsort(want[:, 9], kind="stable")]
+    assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 2e-6
+    assert np.abs(got[:, 6:9] - want[:, 6:9]).max() <= 2e-5 * np.abs(want[:, 6:9]).max()
+    # after a migration every body sits in the key range of the rank that holds it: a second one
+    # right behind it moves nobody
+    grp.migrate()
+    counts = grp.migrate()
+    assert counts.sum() == n and (counts - np.diag(np.diag(counts))).sum() == 0
+    grp.destroy()
+
+
+def test_let_migration_keeps_the_waves_coherent(gpu):
+    """Leavers sort to the ends of their old rank's tree order and make a few waves walk far more
+    cells than the rest; handing them over keeps the longest walk of any wave bounded."""
+    nb = gpu
+    n, world, steps = 60000, 4, 6
+    sp, p = moving(nb, n, 32, 0.3)
+    longest = {}
+    for every in (0, 1):
+        grp = LetGroup(nb, sp, p, world, 0.5, migrate_every=every)
+        for s in grp.sims:
+            s.set_tuning("tree_count_visits", 1)
+        for _ in range(steps):
+            grp.step()
+        longest[every] = max(int(s.debug_buffer("counters", np.uint64)[5]) for s in grp.sims)
+        grp.destroy()
+    assert longest[1] < 0.5 * longest[0], longest
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world):
     """The product class (LetTreeSim: torch.distributed for the three exchanges) as `world`
@@ -255,7 +337,7 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     sp, p0 = tagged(nb, n, 27)
-    grp = LetGroup(nb, sp, p0, world, theta)
+    grp = LetGroup(nb, sp, p0, world, theta, migrate_every=1)   # LetTreeSim's default schedule
     for _ in range(steps):
         grp.step()
     want = by_tag(nb, grp.particles())

@@ -232,6 +232,17 @@ class Simulator:
         arr = (C.c_uint32 * len(counts))(*[int(c) for c in counts])
         check(_lib.lib().nb_sim_let_set_imports(self._h, arr, len(counts)))
 
+    def let_set_owners(self, splits, ref_bound: float, seg_cap: int) -> None:
+        """LET migration (nb_sim_let_set_owners): rank r owns reference keys [splits[r-1], splits[r])."""
+        world = len(splits) + 1
+        arr = (C.c_ulonglong * max(1, len(splits)))(*[int(x) for x in splits])
+        check(_lib.lib().nb_sim_let_set_owners(self._h, arr, world, float(ref_bound), int(seg_cap)))
+
+    def let_set_arrivals(self, stay: int, counts) -> None:
+        """LET migration (nb_sim_let_set_arrivals): bodies kept, bodies received from every rank."""
+        arr = (C.c_uint32 * len(counts))(*[int(c) for c in counts])
+        check(_lib.lib().nb_sim_let_set_arrivals(self._h, int(stay), arr, len(counts)))
+
     # -- Simulator::cleanup --
     def cleanup(self) -> None:
         check(_lib.lib().nb_sim_cleanup(self._h))

@@ -36,6 +36,14 @@ class SimBase {
         set_error("let_set_imports: not a TreeSim");
         return NB_ERR_UNSUPPORTED;
     }
+    virtual int let_set_owners(const unsigned long long *, int, float, uint32_t) {
+        set_error("let_set_owners: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
+    virtual int let_set_arrivals(uint32_t, const uint32_t *, int) {
+        set_error("let_set_arrivals: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int read_tree(nb_octant *, size_t, size_t *, float *) {
         set_error("read_tree: not a TreeSim");
         return NB_ERR_UNSUPPORTED;

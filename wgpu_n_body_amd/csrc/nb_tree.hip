@@ -754,6 +754,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
         atomicAdd(&counters[2], (unsigned long long)st.wave_cells);
         atomicMax(&counters[3], (unsigned long long)st.max_sp);
         atomicAdd(&counters[4], (unsigned long long)st.wave_leaves);
+        atomicMax(&counters[5], (unsigned long long)st.wave_cells);  // the longest walk of any wave
     }
     if (!valid) return;
     const float gdt = g * dt;
@@ -856,29 +857,59 @@ __global__ __launch_bounds__(256) void let_export_level_kernel(
     if (!(blo[0] <= bhi[0])) return;  // the peer has no bodies: nothing to export
     uint32_t *slots = out_slot + (size_t)q * n_cap;
     NodeRec *out = send + (size_t)q * cap;
-    for (uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x; id < end;
-         id += gridDim.x * blockDim.x) {
-        const uint32_t slot = depth == 0 ? 0u : slots[id];
-        if (slot >= cap) continue;  // ~0: not reached for this peer
-        const NodeRec r = rec[id];
-        NodeRec o{r.cogm, 0u, 0u, ~0u, -1.0f};  // terminal: a body / pseudo-body for the peer
-        if (r.count != 0u) {
-            // nearest point of the box to the centre of gravity, per axis, then r^2 in the walk's order
-            const float dx = r.cogm.x - fminf(fmaxf(r.cogm.x, blo[0]), bhi[0]);
-            const float dy = r.cogm.y - fminf(fmaxf(r.cogm.y, blo[1]), bhi[1]);
-            const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
-            const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (!prune || !(r.ssize2 < theta2 * r2)) {  // some point of the box may open it: export the children
-                const uint32_t base = atomicAdd(&counts[q], r.count);
-                if (base + r.count <= cap && r.first + r.count <= n_nodes) {
-                    for (uint32_t c = 0; c < r.count; ++c) slots[r.first + c] = base + c;
-                    o = NodeRec{r.cogm, base, r.count, ~0u, r.ssize2};
+    // A block takes 256 consecutive nodes at a time and allocates the output slots of all their
+    // children with ONE atomic (block-wide scan of the child counts): children of neighbouring
+    // cells stay neighbours in the export, which is what the importer's caches want, and the
+    // counter sees 1/256 of the traffic.
+    __shared__ uint32_t s_wave[4], s_base;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t chunk = begin + blockIdx.x * blockDim.x; chunk < end; chunk += gridDim.x * blockDim.x) {
+        const uint32_t id = chunk + threadIdx.x;
+        uint32_t slot = ~0u, want = 0u;
+        NodeRec r{};
+        if (id < end) {
+            slot = depth == 0 ? 0u : slots[id];
+            if (slot < cap) {  // (~0: not reached for this peer)
+                r = rec[id];
+                if (r.count != 0u) {
+                    // nearest point of the box to the centre of gravity, per axis, then r^2 in the walk's order
+                    const float dx = r.cogm.x - fminf(fmaxf(r.cogm.x, blo[0]), bhi[0]);
+                    const float dy = r.cogm.y - fminf(fmaxf(r.cogm.y, blo[1]), bhi[1]);
+                    const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
+                    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    // some point of the box may open it: export the children too
+                    if ((!prune || !(r.ssize2 < theta2 * r2)) && r.first + r.count <= n_nodes) want = r.count;
+                }
+            }
+        }
+        uint32_t incl = want;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += y;
+        }
+        if (lane == 63u) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0u;
+        for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = total ? atomicAdd(&counts[q], total) : 0u;
+        }
+        __syncthreads();
+        if (slot < cap) {
+            NodeRec o{r.cogm, 0u, 0u, ~0u, -1.0f};  // terminal: a body / pseudo-body for the peer
+            if (want) {
+                const uint32_t base = s_base + before + incl - want;
+                if (base + want <= cap) {
+                    for (uint32_t c = 0; c < want; ++c) slots[r.first + c] = base + c;
+                    o = NodeRec{r.cogm, base, want, ~0u, r.ssize2};
                 } else {
                     atomicAdd(&status[0], 1u);  // capacity exceeded: reported by check_status
                 }
             }
+            out[slot] = o;
         }
-        out[slot] = o;
+        __syncthreads();  // s_wave / s_base are reused by the next chunk
     }
 }
 
@@ -887,6 +918,88 @@ __global__ __launch_bounds__(256) void let_export_level_kernel(
 __global__ void let_clamp_counts_kernel(uint32_t *__restrict__ counts, int world, uint32_t cap) {
     const int q = threadIdx.x;
     if (q < world) counts[q] = min(counts[q], cap);
+}
+
+// ---- migration: a body belongs to the rank whose Morton-key range (in a fixed reference cube)
+// holds its position.  Bodies that left are packed per destination, the rest are compacted;
+// the order inside the arrays is irrelevant (every step re-sorts).
+struct LetOwners {
+    uint32_t world;
+    float ref_bound;                        // the reference cube is [-ref_bound, ref_bound]^3
+    unsigned long long split[kLetMaxWorld]; // rank r owns keys in [split[r-1], split[r]); split[world-1] = inf
+};
+
+__device__ __forceinline__ unsigned long long let_spread21(unsigned long long v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long let_ref_key(float4 p, float ref_bound) {
+    const double b = (double)ref_bound;
+    unsigned long long q[3];
+    const float c[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double t = ((double)c[k] + b) / (2.0 * b) * 2097152.0;
+        t = t < 0.0 ? 0.0 : (t > 2097151.0 ? 2097151.0 : t);   // NaN falls through to the cast: 0
+        q[k] = (unsigned long long)t;
+    }
+    return let_spread21(q[0]) | (let_spread21(q[1]) << 1) | (let_spread21(q[2]) << 2);
+}
+
+// stayers -> dst arrays (compacted), leavers -> send segment of their owner (12 floats per body)
+__global__ __launch_bounds__(256) void let_migrate_kernel(
+    const float4 *__restrict__ posm, const float4 *__restrict__ vel, const float4 *__restrict__ acc,
+    uint32_t n, LetOwners own, int rank, float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst,
+    float4 *__restrict__ acc_dst, float4 *__restrict__ send, uint32_t seg_cap,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_cnt[kLetMaxWorld], s_base[kLetMaxWorld];
+    if (threadIdx.x < kLetMaxWorld) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t dest = 0, local = 0;
+    float4 p{}, v{}, a{};
+    if (i < n) {
+        p = posm[i];
+        v = vel[i];
+        a = acc[i];
+        const unsigned long long key = let_ref_key(p, own.ref_bound);
+        while (dest + 1 < own.world && key >= own.split[dest]) ++dest;
+        local = atomicAdd(&s_cnt[dest], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < own.world)
+        s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    if (i >= n) return;
+    const uint32_t slot = s_base[dest] + local;
+    if ((int)dest == rank) {
+        posm_dst[slot] = p;   // slot < n: stayers never outnumber the bodies
+        vel_dst[slot] = v;
+        acc_dst[slot] = a;
+    } else if (slot < seg_cap) {
+        float4 *o = send + ((size_t)dest * seg_cap + slot) * 3;
+        o[0] = p;
+        o[1] = v;
+        o[2] = a;
+    } else {
+        atomicAdd(&status[0], 1u);  // more leavers than the segment holds: reported by check_status
+    }
+}
+
+__global__ void let_append_kernel(const float4 *__restrict__ recv, uint32_t count, uint32_t at,
+                                  float4 *__restrict__ posm, float4 *__restrict__ vel,
+                                  float4 *__restrict__ acc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    posm[at + i] = recv[3 * (size_t)i + 0];
+    vel[at + i] = recv[3 * (size_t)i + 1];
+    acc[at + i] = recv[3 * (size_t)i + 2];
 }
 
 struct LetSegments {
@@ -960,6 +1073,7 @@ class TreeSim final : public SimBase {
             return NB_ERR_INVALID;
         }
         theta = add.theta > 0.f ? add.theta : NB_DEFAULT_THETA;
+        n_capacity = n;
         const size_t nn = n ? n : 1;
         node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
@@ -1072,6 +1186,7 @@ class TreeSim final : public SimBase {
     // the position all-gather of the previous step has landed and lets the other two overlap it.
     int encode_phase(int phase) override {
         if (int rc = bind_device()) return rc;
+        if (phase == NB_PHASE_LET_MIGRATE) return let_migrate();
         if (phase >= NB_PHASE_LET_META && phase <= NB_PHASE_LET_WALK) return let_phase(phase);
         if (phase != 0 && phase != 1) {
             set_error("encode_phase: phase must be 0 or 1 (or a NB_PHASE_LET_* value)");
@@ -1121,8 +1236,9 @@ class TreeSim final : public SimBase {
             set_error("LET phase %d: set tree_let_world, tree_let_rank and tree_let_cap first", phase);
             return NB_ERR_INVALID;
         }
-        if (phase != let_next) {
-            set_error("LET phases must run in order: expected %d, got %d", let_next, phase);
+        if (phase != let_next || let_arrivals_pending) {
+            set_error("LET phases must run in order: expected %d, got %d%s", let_next, phase,
+                      let_arrivals_pending ? " (a migration awaits nb_sim_let_set_arrivals)" : "");
             return NB_ERR_INVALID;
         }
         const int s = cur;
@@ -1189,6 +1305,90 @@ class TreeSim final : public SimBase {
         step_num += 1;
         let_next = NB_PHASE_LET_META;
         return NB_OK;
+    }
+
+    // NB_PHASE_LET_MIGRATE (optional, before NB_PHASE_LET_META): re-home the bodies whose position
+    // left the rank's Morton-key range.  Stayers are compacted, leavers packed per owner into
+    // region 5, counts (stayers at [rank]) into region 4; the caller all-gathers region 4, moves
+    // the segments into region 6 and calls nb_sim_let_set_arrivals.
+    int let_migrate() {
+        if (!let_world || !let_send || !let_mig_send) {
+            set_error("LET migrate: set tree_let_world / rank / cap and the owners (nb_sim_let_set_owners) first");
+            return NB_ERR_INVALID;
+        }
+        if (let_next != NB_PHASE_LET_META) {
+            set_error("LET migrate: only between steps");
+            return NB_ERR_INVALID;
+        }
+        const int s = cur, d = cur ^ 1;
+        uint32_t *my_counts = let_mig_counts + (size_t)let_rank * let_world;
+        NB_HIP_TRY(hipMemsetAsync(my_counts, 0, sizeof(uint32_t) * let_world, stream));
+        if (n)
+            hipLaunchKernelGGL(let_migrate_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, posm[s], vel[s],
+                               acc[s], n, let_owners, let_rank, posm[d], vel[d], acc[d], let_mig_send,
+                               let_mig_cap, my_counts, scalars + 4);
+        NB_HIP_TRY(hipGetLastError());
+        cur = d;  // the compacted stayers are the state now (their number: counts[rank])
+        let_arrivals_pending = true;
+        return NB_OK;
+    }
+
+    int let_set_owners(const unsigned long long *splits, int world, float ref_bound, uint32_t seg_cap) override {
+        if (!let_world || world != let_world || !splits || !(ref_bound > 0.f) || seg_cap == 0) {
+            set_error("let_set_owners: bad arguments (world %d, tree_let_world %d)", world, let_world);
+            return NB_ERR_INVALID;
+        }
+        if (int rc = bind_device()) return rc;
+        let_owners.world = (uint32_t)world;
+        let_owners.ref_bound = ref_bound;
+        for (int r = 0; r < world; ++r) let_owners.split[r] = r + 1 < world ? splits[r] : ~0ull;
+        if (!let_mig_send) {
+            const size_t w = (size_t)world;
+            let_mig_cap = seg_cap;
+            if (int rc = alloc(&let_mig_counts, sizeof(uint32_t) * w * w)) return rc;
+            if (int rc = alloc(&let_mig_send, sizeof(float4) * 3 * w * (size_t)seg_cap)) return rc;
+            if (int rc = alloc(&let_mig_recv, sizeof(float4) * 3 * w * (size_t)seg_cap)) return rc;
+            NB_HIP_TRY(hipMemsetAsync(let_mig_counts, 0, sizeof(uint32_t) * w * w, stream));
+            NB_HIP_TRY(hipStreamSynchronize(stream));
+        }
+        return NB_OK;
+    }
+
+    // after the exchange: `stay` bodies were kept, counts[r] arrived from rank r (packed in rank
+    // order in region 6); the simulator's body count becomes stay + sum(counts)
+    int let_set_arrivals(uint32_t stay, const uint32_t *counts, int world) override {
+        if (!let_arrivals_pending || world != let_world || !counts) {
+            set_error("let_set_arrivals: no migration in flight (or world mismatch)");
+            return NB_ERR_INVALID;
+        }
+        if (int rc = bind_device()) return rc;
+        uint64_t total = 0;
+        for (int r = 0; r < world; ++r) total += (r == let_rank) ? 0u : counts[r];
+        if (stay > n || stay + total > n_capacity || total > (uint64_t)let_mig_cap * world) {
+            set_error("let_set_arrivals: %u kept + %llu arrived exceed the capacity of %u bodies", stay,
+                      (unsigned long long)total, n_capacity);
+            return NB_ERR_UNSUPPORTED;
+        }
+        if (total)
+            hipLaunchKernelGGL(let_append_kernel, dim3(((uint32_t)total + 255) / 256), dim3(256), 0, stream,
+                               let_mig_recv, (uint32_t)total, stay, posm[cur], vel[cur], acc[cur]);
+        NB_HIP_TRY(hipGetLastError());
+        set_active(stay + (uint32_t)total);
+        let_arrivals_pending = false;
+        return NB_OK;
+    }
+
+    // the number of bodies this simulator currently holds (<= the capacity it was created with)
+    void set_active(uint32_t count) {
+        n = count;
+        hi = count;
+        lo = 0;
+        params.particle_num = count;
+        const size_t nn = n ? n : 1;
+        sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
+        id_blocks = (uint32_t)((nn + kIdThreads - 1) / kIdThreads);
+        scan_blocks = (uint32_t)((nn + kScanTile - 1) / kScanTile);
+        mom_blocks = (uint32_t)((nn + 1 + kMomTile - 1) / kMomTile);
     }
 
     int let_set_imports(const uint32_t *counts, int world) override {
@@ -1435,11 +1635,12 @@ class TreeSim final : public SimBase {
     // rank), 1 export counts (all-gather, one row of `world` u32 per rank), 2 the export segments
     // (segment q = records for peer q, stride = slice_bytes), 3 the import area (packed by the
     // caller in rank order, skipping itself).
-    int exchange_count() override { return let_world ? 4 : 3; }
+    int exchange_count() override { return let_world ? (let_mig_send ? 7 : 4) : 3; }
     int exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) override {
         if (let_world) {
-            if (index < 0 || index > 3 || !let_send) {
-                set_error("LET exchange region %d out of range (4 regions, after tree_let_cap is set)", index);
+            if (index < 0 || index > (let_mig_send ? 6 : 3) || !let_send) {
+                set_error("LET exchange region %d out of range (4 regions after tree_let_cap is set, 7 with "
+                          "nb_sim_let_set_owners)", index);
                 return NB_ERR_INVALID;
             }
             const size_t w = (size_t)let_world;
@@ -1449,7 +1650,12 @@ class TreeSim final : public SimBase {
             case 0: base = let_meta; l = sizeof(uint32_t) * kLetMetaWords; o = l * let_rank; t = l * w; break;
             case 1: base = let_counts; l = sizeof(uint32_t) * w; o = l * let_rank; t = l * w; break;
             case 2: base = let_send; l = sizeof(NodeRec) * (size_t)let_cap; t = l * w; break;
-            default: base = rec + node_cap; l = sizeof(NodeRec) * (size_t)let_cap; t = l * w; break;
+            case 3: base = rec + node_cap; l = sizeof(NodeRec) * (size_t)let_cap; t = l * w; break;
+            // migration: 4 counts (all-gather, `world` u32 per rank, stayers at [rank]), 5 leavers per
+            // owner (48 B per body, segment stride = slice_bytes), 6 arrivals (packed in rank order)
+            case 4: base = let_mig_counts; l = sizeof(uint32_t) * w; o = l * let_rank; t = l * w; break;
+            case 5: base = let_mig_send; l = sizeof(float4) * 3 * (size_t)let_mig_cap; t = l * w; break;
+            default: base = let_mig_recv; l = sizeof(float4) * 3 * (size_t)let_mig_cap; t = l * w; break;
             }
             if (dev_ptr) *dev_ptr = base;
             if (off) *off = o;
@@ -1486,6 +1692,14 @@ class TreeSim final : public SimBase {
         }
         if (std::strcmp(key, "tree_let_rank") == 0) {
             let_rank = value;
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_let_active") == 0) {  // bodies in use; the rest of the capacity is headroom
+            if (value < 0 || (uint32_t)value > n_capacity || !let_world) {
+                set_error("tree_let_active: %d out of range (capacity %u; LET mode only)", value, n_capacity);
+                return NB_ERR_INVALID;
+            }
+            set_active((uint32_t)value);
             return NB_OK;
         }
         if (std::strcmp(key, "tree_let_prune") == 0) {  // 0: export whole trees (testing: same result)
@@ -1558,7 +1772,11 @@ class TreeSim final : public SimBase {
     uint32_t *let_meta = nullptr, *let_counts = nullptr, *let_out_slot = nullptr;
     NodeRec *let_send = nullptr;
     LetSegments let_segs{};
-    bool let_imports_set = false, let_prune = true;
+    bool let_imports_set = false, let_prune = true, let_arrivals_pending = false;
+    uint32_t n_capacity = 0, let_mig_cap = 0;
+    uint32_t *let_mig_counts = nullptr;
+    float4 *let_mig_send = nullptr, *let_mig_recv = nullptr;
+    LetOwners let_owners{};
     hipGraphExec_t graph_exec = nullptr;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;

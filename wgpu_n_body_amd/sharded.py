@@ -21,7 +21,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import (AddParams, NaiveSim, Placement, SimParams, TreeSim, as_floats, as_particles,
+from . import (AddParams, NaiveSim, NBodyError, Placement, SimParams, TreeSim, as_floats, as_particles,
                shard_bodies_per_rank)
 
 
@@ -269,15 +269,14 @@ class ShardedTreeSim:
         self.sim.destroy()
 
 
-def morton_order(particles: np.ndarray) -> np.ndarray:
-    """Indices that sort bodies along a Morton (Z-order) curve of their positions -- used only to
-    hand every rank a compact spatial domain at start-up (any space-filling order would do; the
-    octree itself is keyed on the device by the reference's own descent)."""
+def _morton_keys(particles: np.ndarray) -> np.ndarray:
+    """63-bit Morton keys of the positions quantised to 21 bits per axis in the cube
+    [-bound, bound]^3, bound = max |coordinate| (as a float32, the value the device is given):
+    the same arithmetic as let_ref_key in nb_tree.hip."""
     f = as_floats(particles)
     pos = f[:, 0:3].astype(np.float64)
-    lo, hi = pos.min(axis=0), pos.max(axis=0)
-    span = np.maximum(hi - lo, 1e-30)
-    q = np.minimum(((pos - lo) / span * 2097152.0).astype(np.uint64), np.uint64(2097151))  # 21 bits/axis
+    bound = float(np.float32(max(float(np.abs(f[:, 0:3]).max()), 1e-30)))
+    q = np.clip((pos + bound) / (2.0 * bound) * 2097152.0, 0.0, 2097151.0).astype(np.uint64)
 
     def spread(v):  # insert two zero bits after each of the 21 low bits
         v = v & np.uint64(0x1fffff)
@@ -288,16 +287,60 @@ def morton_order(particles: np.ndarray) -> np.ndarray:
         v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
         return v
 
-    key = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
-    return np.argsort(key, kind="stable")
+    return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+
+
+def morton_order(particles: np.ndarray) -> np.ndarray:
+    """Indices that sort bodies along a Morton (Z-order) curve of their positions -- used only to
+    hand every rank a compact spatial domain at start-up (any space-filling order would do; the
+    octree itself is keyed on the device by the reference's own descent)."""
+    return np.argsort(_morton_keys(particles), kind="stable")
+
+
+def morton_domains(particles: np.ndarray, world: int, slack: float = 0.02, with_owners: bool = False):
+    """(order, cuts): bodies in Morton order and `world`+1 cut positions; rank r owns
+    order[cuts[r]:cuts[r+1]].  Each cut starts at the equal-count position and snaps to the
+    border of the COARSEST octree cell that lies within `slack` x (bodies per rank) of it: a
+    domain that ends on a cell border has a tight bounding box, while a handful of bodies from
+    the next cell would stretch the box -- and with it every peer's export -- across that cell.
+    with_owners: also return (splits, ref_bound) for nb_sim_let_set_owners -- the first key of every
+    domain but the first, and the half-width of the cube the keys were quantised in."""
+    keys = _morton_keys(particles)
+    order = np.argsort(keys, kind="stable")
+    skeys = keys[order]
+    n = len(order)
+    cuts = [0]
+    tol = max(1, int(slack * n / max(world, 1)))
+    for r in range(1, world):
+        c0 = (n * r) // world
+        best = c0
+        lo, hi = max(c0 - tol, cuts[-1] + 1), min(c0 + tol, n - 1)
+        if lo <= hi and n > 1:
+            for level in range(1, 22):                 # coarsest first
+                shift = np.uint64(3 * (21 - level))
+                seg = skeys[lo - 1:hi + 1] >> shift
+                change = np.nonzero(seg[1:] != seg[:-1])[0]          # border between lo-1+j and lo+j
+                if len(change):
+                    cand = lo + change
+                    best = int(cand[np.argmin(np.abs(cand - c0))])
+                    break
+        cuts.append(max(best, cuts[-1]))
+    cuts.append(n)
+    if not with_owners:
+        return order, cuts
+    # an empty tail domain owns nothing: its border is "past every key"
+    splits = [int(skeys[c]) if c < n else (1 << 63) for c in cuts[1:-1]]
+    pos = as_floats(particles)[:, 0:3]
+    return order, cuts, splits, max(float(np.abs(pos).max()), 1e-30)
 
 
 class LetTreeSim:
     """Barnes-Hut on several GPUs, SURVEY 8(e) step 2: Morton-range domains, local octrees and a
     locally-essential-tree (LET) exchange (nb_sim_encode_phase(NB_PHASE_LET_*), include/nbody.h).
 
-    Start-up: the bodies are ordered along a Morton curve and cut into `world` equal runs; rank r
-    keeps run r for good (velocities and accelerations never leave their owner).  Per step:
+    Start-up: the bodies are ordered along a Morton curve and cut into `world` near-equal runs
+    whose ends sit on octree-cell borders (morton_domains); rank r keeps run r for good
+    (velocities and accelerations never leave their owner).  Per step:
       1. NB_PHASE_LET_META  -> all-gather 32 B per rank (local bound, box of the drifted bodies);
       2. NB_PHASE_LET_BUILD -> every rank builds the octree of ITS bodies inside the global root
          cube and prunes it against each peer's box; all-gather the `world` export counts, read
@@ -307,13 +350,18 @@ class LetTreeSim:
     per-body acceptance test); the pruning is decision-exact, so the result does not depend on
     the peers' boxes or on the exchange -- only on which bodies share a domain.
 
-    Bodies are not migrated: a domain is "the bodies a rank started with", its box follows them.
-    `rebalance()` (collective) re-cuts the domains from the current positions."""
+    Migration: a domain is a range of Morton keys in the start-up cube; every `migrate_every`
+    steps (default: every step) the bodies that left their rank's range are handed to the new
+    owner (NB_PHASE_LET_MIGRATE: one more small all-gather, host read and all-to-all).  Without
+    it the leavers sort to the ends of their old rank's tree order, where they form spatially
+    incoherent waves whose walks are ten times longer than the rest.  `rebalance()` (collective,
+    host-side) re-cuts the domains from the current positions when the load has drifted."""
 
-    META, BUILD, WALK = 2, 3, 4
+    META, BUILD, WALK, MIGRATE = 2, 3, 4, 5
+    HEADROOM = 1.25     # body capacity of a rank relative to its start-up share
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
-                 device_index: int, group=None, let_cap: Optional[int] = None):
+                 device_index: int, group=None, let_cap: Optional[int] = None, migrate_every: int = 1):
         import torch
         self._torch = torch
         self.rank, self.world, self.group = rank, world, group
@@ -325,33 +373,36 @@ class LetTreeSim:
         self.sim = None
         self.step_num = 0
         self._let_cap = let_cap
+        self.migrate_every = int(migrate_every)
         self._adopt(as_particles(particles))
 
     # -- domain set-up -------------------------------------------------------------------------
     def _adopt(self, particles: np.ndarray) -> None:
-        order = morton_order(particles)
-        cuts = [(len(order) * r) // self.world for r in range(self.world + 1)]
+        order, cuts, splits, ref_bound = morton_domains(particles, self.world, with_owners=True)
         self.counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
-        mine = np.ascontiguousarray(particles[order[cuts[self.rank]:cuts[self.rank + 1]]])
+        mine = particles[order[cuts[self.rank]:cuts[self.rank + 1]]]
         if self.sim is not None:
             self.sim.destroy()
-        sp = SimParams(particle_num=len(mine), g=self.params.g, e=self.params.e, dt=self.params.dt)
-        self.sim = TreeSim.from_particles(sp, AddParams.TreeSimParams(self.theta), mine,
+        capacity = int(self.HEADROOM * max(self.counts)) + 4096
+        padded = np.zeros(capacity, dtype=mine.dtype)
+        padded[:len(mine)] = mine
+        sp = SimParams(particle_num=capacity, g=self.params.g, e=self.params.e, dt=self.params.dt)
+        self.sim = TreeSim.from_particles(sp, AddParams.TreeSimParams(self.theta), padded,
                                           Placement(self._device_index, 0, 1, self.stream.cuda_stream))
-        # a peer can need at most this rank's whole octree (< 2 n_local + 1 nodes for distinct
-        # bodies); default to that, capped to keep 2 x world x cap x 32 B reasonable
-        cap = self._let_cap or max(4096, 2 * max(self.counts) + 64)
+        # a peer can need at most this rank's whole octree (< 2 n + 1 nodes for distinct bodies)
+        cap = self._let_cap or (2 * capacity + 64)
         self.sim.set_tuning("tree_let_world", self.world)
         self.sim.set_tuning("tree_let_rank", self.rank)
+        self.sim.set_tuning("tree_let_active", len(mine))
         self.sim.set_tuning("tree_let_cap", int(cap))
         self.cap = int(cap)
+        self.mig_cap = max(1024, capacity // 8)       # leavers per destination per migration
+        self.sim.let_set_owners(splits, ref_bound, self.mig_cap)
         t = self._torch
         self._views = []
-        for k in range(4):
+        for k in range(self.sim.exchange_count()):
             ptr, off, ln, tot = self.sim.exchange_region(k)
             self._views.append((t.as_tensor(_DevicePtr(ptr, tot // 4), device=self._dev), off // 4, ln // 4))
-        self._pinned_counts = t.empty(self.world * self.world, dtype=t.int32).pin_memory() \
-            if t.cuda.is_available() else None
 
     # -- one step --------------------------------------------------------------------------------
     def _all_gather(self, k: int) -> None:
@@ -360,15 +411,15 @@ class LetTreeSim:
         if self.world > 1:
             dist.all_gather_into_tensor(full, full[off:off + ln], group=self.group)
 
-    def _exchange_segments(self, counts: np.ndarray) -> list:
-        """Move counts[r][me] records of rank r's segment `me` into the import area, packed in
-        rank order.  RCCL: one grouped all-to-all on device views.  Other backends (the gloo
-        rehearsal): point-to-point through host memory."""
+    def _exchange_segments(self, counts: np.ndarray, k_send: int, k_recv: int, R: int) -> list:
+        """Move counts[r][me] records (R floats each) of rank r's segment `me` of region k_send
+        into region k_recv, packed in rank order.  RCCL: one grouped all-to-all on device views.
+        Other backends (the gloo rehearsal): point-to-point through host memory."""
         import torch.distributed as dist
         t = self._torch
-        send, _, seg = self._views[2]
-        recv, _, _ = self._views[3]
-        me, W, R = self.rank, self.world, 8          # R = floats per 32-byte record
+        send, _, seg = self._views[k_send]
+        recv, _, _ = self._views[k_recv]
+        me, W = self.rank, self.world
         recv_counts = [0 if r == me else int(counts[r, me]) for r in range(W)]
         send_counts = [0 if q == me else int(counts[me, q]) for q in range(W)]
         offs = np.concatenate([[0], np.cumsum(recv_counts)])
@@ -398,16 +449,35 @@ class LetTreeSim:
                 outs[r].copy_(host_out[r])
         return recv_counts
 
+    def _counts_matrix(self, k: int) -> np.ndarray:
+        t = self._torch
+        self._all_gather(k)
+        return self._views[k][0].view(t.int32).cpu().numpy().astype(np.int64).reshape(self.world, self.world)
+
+    def migrate(self) -> None:
+        """Hand the bodies that left this rank's key range to their new owners (collective)."""
+        t = self._torch
+        with t.cuda.stream(self.stream):
+            self.sim.encode_phase(self.MIGRATE)
+            counts = self._counts_matrix(4)
+            if (counts - np.diag(np.diag(counts))).max(initial=0) > self.mig_cap:
+                raise NBodyError("LET migration: more leavers for one rank than the segment holds "
+                                 f"({int(counts.max())} > {self.mig_cap}); rebalance() first")
+            recv = self._exchange_segments(counts, 5, 6, 12)
+            self.sim.let_set_arrivals(int(counts[self.rank, self.rank]), recv)
+        self.counts = [int(counts[:, r].sum()) for r in range(self.world)]
+        self.last_migration = counts
+
     def encode(self) -> None:
         t = self._torch
+        if self.migrate_every > 0 and self.step_num > 0 and self.step_num % self.migrate_every == 0:
+            self.migrate()
         with t.cuda.stream(self.stream):
             self.sim.encode_phase(self.META)
             self._all_gather(0)
             self.sim.encode_phase(self.BUILD)
-            self._all_gather(1)
-            counts_dev = self._views[1][0].view(t.int32)
-            counts = counts_dev.cpu().numpy().astype(np.int64).reshape(self.world, self.world)
-            recv_counts = self._exchange_segments(counts)
+            counts = self._counts_matrix(1)
+            recv_counts = self._exchange_segments(counts, 2, 3, 8)
             self.last_counts = counts
             self.sim.let_set_imports(recv_counts)
             self.sim.encode_phase(self.WALK)
