@@ -71,3 +71,33 @@ def test_all_pairs_oracle_is_reflection_equivariant(oracle, points, axis):
     b = oracle.naive_step_f32(m, G, E, DT)
     b[:, [axis, 3 + axis, 6 + axis]] *= -1
     assert np.array_equal(a, b, equal_nan=True)   # value equality: -0.0 == 0.0
+
+
+def test_morton_domains_cut_on_cell_borders():
+    """Start-up domains of the LET scheme: a permutation, near-equal counts, cuts that sit on
+    octree-cell borders (8 ranks on a uniform cube = the 8 octants), splits = first key of each
+    domain, and degenerate sizes do not break it."""
+    import wgpu_n_body_amd as nb
+    from wgpu_n_body_amd.sharded import _morton_keys, morton_domains
+    sp = nb.SimParams(particle_num=400000)
+    p = nb.inits.uniform_init(sp, seed=3)
+    order, cuts, splits, ref = morton_domains(p, 8, with_owners=True)
+    assert sorted(order.tolist()) == list(range(400000))
+    assert cuts[0] == 0 and cuts[-1] == 400000 and all(b >= a for a, b in zip(cuts, cuts[1:]))
+    counts = np.diff(cuts)
+    assert counts.min() > 0.98 * 50000 and counts.max() < 1.02 * 50000
+    pos = nb.as_floats(p)[order][:, 0:3]
+    for r in range(8):
+        d = pos[cuts[r]:cuts[r + 1]]
+        sign = [(r >> k) & 1 for k in range(3)]             # x is the lowest key bit of a level
+        for k in range(3):
+            assert (d[:, k] >= 0).all() if sign[k] else (d[:, k] <= 0).all()
+    keys = np.sort(_morton_keys(p))
+    assert splits == [int(keys[c]) for c in cuts[1:-1]] and splits == sorted(splits)
+    assert 0.99 < ref <= 1.0
+    for n, w in ((7, 4), (1, 2), (2, 4), (0, 3)):
+        q = nb.inits.uniform_init(nb.SimParams(particle_num=max(n, 1)), seed=1)[:n]
+        if n == 0:
+            continue
+        o, c = morton_domains(q, w)
+        assert sorted(o.tolist()) == list(range(n)) and c[0] == 0 and c[-1] == n and len(c) == w + 1

@@ -26,7 +26,7 @@ import torch  # noqa: E402  (first: torch bundles its own HIP runtime)
 import wgpu_n_body_amd as nb  # noqa: E402
 from wgpu_n_body_amd.sharded import morton_domains  # noqa: E402
 
-META, BUILD, WALK = 2, 3, 4
+META, BUILD, WALK, MIGRATE = 2, 3, 4, 5
 REC = 32
 
 
@@ -39,6 +39,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--init", default="uniform")
+    ap.add_argument("--migrate-every", type=int, default=1)
     ap.add_argument("--skip-baselines", action="store_true")
     ap.add_argument("--count-visits", action="store_true", help="one extra counted step at the end")
     args = ap.parse_args()
@@ -49,25 +50,31 @@ def main() -> None:
     p = getattr(nb.inits, args.init + "_init")(sp, seed=args.seed)
 
     t0 = time.perf_counter()
-    order, cuts = morton_domains(p, W)
+    order, cuts, splits, ref_bound = morton_domains(p, W, with_owners=True)
     t_order = time.perf_counter() - t0
     one = torch.cuda.Stream(dev)   # all ranks on ONE stream: each rank's kernels run alone, back to back
     streams = [one for _ in range(W)]
     sims = []
+    capacity = int(1.25 * max(cuts[r + 1] - cuts[r] for r in range(W))) + 4096
+    mig_cap = max(1024, capacity // 8)
     for r in range(W):
-        mine = np.ascontiguousarray(p[order[cuts[r]:cuts[r + 1]]])
-        s = nb.TreeSim.from_particles(nb.SimParams(particle_num=len(mine)), nb.AddParams.TreeSimParams(args.theta),
-                                      mine, nb.Placement(0, 0, 1, streams[r].cuda_stream))
+        mine = p[order[cuts[r]:cuts[r + 1]]]
+        padded = np.zeros(capacity, dtype=mine.dtype)
+        padded[:len(mine)] = mine
+        s = nb.TreeSim.from_particles(nb.SimParams(particle_num=capacity), nb.AddParams.TreeSimParams(args.theta),
+                                      padded, nb.Placement(0, 0, 1, streams[r].cuda_stream))
         s.set_tuning("tree_let_world", W)
         s.set_tuning("tree_let_rank", r)
-        s.set_tuning("tree_let_cap", 2 * len(mine) + 64)
+        s.set_tuning("tree_let_active", len(mine))
+        s.set_tuning("tree_let_cap", 2 * capacity + 64)
+        s.let_set_owners(splits, ref_bound, mig_cap)
         sims.append(s)
 
     def view(ptr, nbytes):
         from wgpu_n_body_amd.sharded import _DevicePtr
         return torch.as_tensor(_DevicePtr(ptr, nbytes // 4), device=dev)
 
-    regs = [[s.exchange_region(k) for k in range(4)] for s in sims]
+    regs = [[s.exchange_region(k) for k in range(7)] for s in sims]
     views = [[view(ptr, tot) for (ptr, _o, _l, tot) in rg] for rg in regs]
 
     def all_gather(k):
@@ -91,10 +98,44 @@ def main() -> None:
         for _ in range(32):
             warm.encode()
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(W)]
-    acc = np.zeros((W, 3))
+    def all_to_all(counts, k_send, k_recv, R):
+        received = []
+        for me in range(W):
+            offs, recv = 0, []
+            for r in range(W):
+                c = 0 if r == me else int(counts[r, me])
+                recv.append(c)
+                if c:
+                    seg = regs[r][k_send][2] // 4
+                    views[me][k_recv][offs * R:(offs + c) * R].copy_(views[r][k_send][me * seg:me * seg + c * R])
+                offs += c
+            received.append(recv)
+        torch.cuda.synchronize()
+        return received
+
+    def matrix(k):
+        all_gather(k)
+        return views[0][k].view(torch.int32).cpu().numpy().astype(np.int64).reshape(W, W)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(8)] for _ in range(W)]
+    acc = np.zeros((W, 4))
+    migrated = 0
     let_records = None
     for it in range(args.warmup + args.steps):
+        do_mig = args.migrate_every > 0 and it > 0 and it % args.migrate_every == 0
+        if do_mig:
+            keep_warm()
+            for r, s in enumerate(sims):
+                with torch.cuda.stream(streams[r]):
+                    ev[r][6].record()
+                    s.encode_phase(MIGRATE)
+                    ev[r][7].record()
+            mc = matrix(4)
+            received = all_to_all(mc, 5, 6, 12)
+            for me, s in enumerate(sims):
+                s.let_set_arrivals(int(mc[me, me]), received[me])
+            if it >= args.warmup:
+                migrated += int(mc.sum() - np.trace(mc))
         keep_warm()
         for r, s in enumerate(sims):
             with torch.cuda.stream(streams[r]):
@@ -108,19 +149,10 @@ def main() -> None:
                 ev[r][2].record()
                 s.encode_phase(BUILD)
                 ev[r][3].record()
-        all_gather(1)
-        counts = views[0][1].view(torch.int32).cpu().numpy().astype(np.int64).reshape(W, W)
+        counts = matrix(1)
+        received = all_to_all(counts, 2, 3, 8)
         for me, s in enumerate(sims):
-            offs, recv = 0, []
-            for r in range(W):
-                c = 0 if r == me else int(counts[r, me])
-                recv.append(c)
-                if c:
-                    seg = regs[r][2][2] // 4
-                    views[me][3][offs * 8:(offs + c) * 8].copy_(views[r][2][me * seg:me * seg + c * 8])
-                offs += c
-            s.let_set_imports(recv)
-        torch.cuda.synchronize()
+            s.let_set_imports(received[me])
         keep_warm()
         for r, s in enumerate(sims):
             with torch.cuda.stream(streams[r]):
@@ -134,7 +166,7 @@ def main() -> None:
         if it >= args.warmup:
             for r in range(W):
                 acc[r] += [ev[r][0].elapsed_time(ev[r][1]), ev[r][2].elapsed_time(ev[r][3]),
-                           ev[r][4].elapsed_time(ev[r][5])]
+                           ev[r][4].elapsed_time(ev[r][5]), ev[r][6].elapsed_time(ev[r][7]) if do_mig else 0.0]
         let_records = counts
     acc /= args.steps
     off = ~np.eye(W, dtype=bool)
@@ -145,6 +177,8 @@ def main() -> None:
         "ms_meta": {"mean": acc[:, 0].mean(), "max": acc[:, 0].max()},
         "ms_build_and_export": {"mean": acc[:, 1].mean(), "max": acc[:, 1].max()},
         "ms_walk": {"mean": acc[:, 2].mean(), "max": acc[:, 2].max()},
+        "ms_migrate": {"mean": acc[:, 3].mean(), "max": acc[:, 3].max()},
+        "migrate_every": args.migrate_every, "bodies_migrated_per_step": migrated / args.steps,
         "ms_rank_total": {"mean": acc.sum(axis=1).mean(), "max": acc.sum(axis=1).max()},
         "ms_walk_per_rank": [round(float(x), 3) for x in acc[:, 2]],
         "let_records_per_pair": {"mean": float(let_records[off].mean()), "max": int(let_records[off].max())},
@@ -161,24 +195,16 @@ def main() -> None:
         all_gather(0)
         for s in sims:
             s.encode_phase(BUILD)
-        all_gather(1)
-        counts = views[0][1].view(torch.int32).cpu().numpy().astype(np.int64).reshape(W, W)
+        counts = matrix(1)
+        received = all_to_all(counts, 2, 3, 8)
         for me, s in enumerate(sims):
-            offs, recv = 0, []
-            for r in range(W):
-                c = 0 if r == me else int(counts[r, me])
-                recv.append(c)
-                if c:
-                    seg = regs[r][2][2] // 4
-                    views[me][3][offs * 8:(offs + c) * 8].copy_(views[r][2][me * seg:me * seg + c * 8])
-                offs += c
-            s.let_set_imports(recv)
-        torch.cuda.synchronize()
+            s.let_set_imports(received[me])
         for s in sims:
             s.encode_phase(WALK)
         cs = [s.debug_buffer("counters", np.uint64) - b for s, b in zip(sims, c_before)]
         out["visits_per_body"] = [float(c[0]) / (n / W) for c in cs]
         out["wave_cells_per_wave"] = [float(c[2]) / (n / W / 64) for c in cs]
+        out["longest_wave_cells"] = [int(s.debug_buffer("counters", np.uint64)[5]) for s in sims]
     for s in sims:
         s.destroy()
     warm.destroy()

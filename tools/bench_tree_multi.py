@@ -1,5 +1,7 @@
 """Barnes-Hut step on several GPUs (BASELINE.json configs[4]: 4,194,304 bodies, theta 0.5, 8 GPUs),
-replicated tree + partitioned walk (ShardedTreeSim).  Launch like bench.py:
+either scheme of SURVEY 8(e): `--scheme let` (default; Morton-range domains, local octrees, LET
+exchange, body migration: LetTreeSim) or `--scheme replicated` (replicated tree + partitioned
+walk: ShardedTreeSim).  Launch like bench.py:
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P tools/bench_tree_multi.py --bodies 4194304 --steps 20 --warmup 5
@@ -20,6 +22,8 @@ ap.add_argument("--theta", type=float, default=0.5)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--scheme", choices=("let", "replicated"), default="let")
+ap.add_argument("--migrate-every", type=int, default=1)
 args = ap.parse_args()
 
 import numpy as np  # noqa: E402
@@ -27,7 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import wgpu_n_body_amd as nb  # noqa: E402
-from wgpu_n_body_amd.sharded import ShardedTreeSim  # noqa: E402
+from wgpu_n_body_amd.sharded import LetTreeSim, ShardedTreeSim  # noqa: E402
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
@@ -50,7 +54,10 @@ def sync_all():
 
 sp = nb.SimParams(particle_num=args.bodies)
 init = nb.inits.uniform_init(sp, seed=5)
-sim = ShardedTreeSim(sp, args.theta, init, rank, world, local_rank, overlap=not args.no_overlap)
+if args.scheme == "let":
+    sim = LetTreeSim(sp, args.theta, init, rank, world, local_rank, migrate_every=args.migrate_every)
+else:
+    sim = ShardedTreeSim(sp, args.theta, init, rank, world, local_rank, overlap=not args.no_overlap)
 for _ in range(args.warmup):
     sim.encode()
 sim.wait()
@@ -67,7 +74,8 @@ wall = float(wall.item())
 state = nb.as_floats(sim.read_particles())
 assert np.isfinite(state).all()
 if rank == 0:
-    print(json.dumps({"metric": "Barnes-Hut step, replicated tree + partitioned walk",
+    print(json.dumps({"metric": "Barnes-Hut step, " + ("Morton-range domains + LET exchange" if args.scheme == "let"
+                                                       else "replicated tree + partitioned walk"),
                       "bodies": args.bodies, "theta": args.theta, "n_gpus": world,
                       "ms_per_step": wall / args.steps * 1e3,
                       "bodies_per_s": args.bodies * args.steps / wall,
