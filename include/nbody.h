@@ -221,6 +221,10 @@ int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world);
  * nb_sim_let_set_arrivals(stayers, arrivals per rank); nb_sim_sim_params then reports the new
  * body count. */
 #define NB_PHASE_LET_MIGRATE 5
+/* Optional, between NB_PHASE_LET_BUILD and NB_PHASE_LET_WALK: walk the rank's own octree (it needs
+ * nothing from the peers) while the exported trees are still being exchanged; NB_PHASE_LET_WALK
+ * then adds the imported trees and integrates.  Same sums in the same order: bit-identical. */
+#define NB_PHASE_LET_WALK_OWN 6
 int nb_sim_let_set_owners(nb_sim *sim, const unsigned long long *splits, int world, float ref_bound,
                           uint32_t seg_cap);
 int nb_sim_let_set_arrivals(nb_sim *sim, uint32_t stay, const uint32_t *counts, int world);

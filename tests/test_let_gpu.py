@@ -20,7 +20,7 @@ from tests.helpers import ROOT, bits
 
 pytestmark = pytest.mark.gpu
 
-META, BUILD, WALK, MIGRATE = 2, 3, 4, 5
+META, BUILD, WALK, MIGRATE, WALK_OWN = 2, 3, 4, 5, 6
 REC = 32  # bytes per exported record
 
 
@@ -53,10 +53,11 @@ def by_tag(nb, particles):
 class LetGroup:
     """`world` TreeSims on one GPU running the LET protocol, exchanges by hipMemcpy."""
 
-    def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0):
+    def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0,
+                 own_first=False):
         from wgpu_n_body_amd.sharded import morton_domains
         self.nb, self.world, self.hip = nb, world, _hip()
-        self.migrate_every, self.steps_done = migrate_every, 0
+        self.migrate_every, self.steps_done, self.own_first = migrate_every, 0, own_first
         order, cuts, splits, ref_bound = morton_domains(particles, world, with_owners=True)
         counts = [cuts[r + 1] - cuts[r] for r in range(world)]
         capacity = int(1.25 * max(counts)) + 4096
@@ -136,6 +137,8 @@ class LetGroup:
         self._all_gather(0)
         for s in self.sims:
             s.encode_phase(BUILD)
+            if self.own_first:
+                s.encode_phase(WALK_OWN)      # while the exchange below is "in flight"
         counts = self._matrix(1)
         self.counts = counts
         received = self._all_to_all(counts, 2, 3, REC)
@@ -261,6 +264,24 @@ def test_let_phases_must_run_in_order(gpu):
     s.encode_phase(WALK)
     s.wait()
     s.destroy()
+
+
+def test_let_own_tree_first_is_the_same_step(gpu):
+    """NB_PHASE_LET_WALK_OWN before the exchange + imports afterwards == one walk over all trees."""
+    nb = gpu
+    sp, p = tagged(nb, 12000, 33)
+    whole = LetGroup(nb, sp, p, 3, 0.5, migrate_every=1)
+    split = LetGroup(nb, sp, p, 3, 0.5, migrate_every=1, own_first=True)
+    for _ in range(4):
+        whole.step()
+        split.step()
+    assert np.array_equal(bits(by_tag(nb, whole.particles())), bits(by_tag(nb, split.particles())))
+    s = split.sims[0]
+    s.encode_phase(META)
+    with pytest.raises(nb.NBodyError):
+        s.encode_phase(WALK_OWN)              # only after the build
+    whole.destroy()
+    split.destroy()
 
 
 def moving(nb, n, seed, speed):

@@ -55,7 +55,8 @@ def sync_all():
 sp = nb.SimParams(particle_num=args.bodies)
 init = nb.inits.uniform_init(sp, seed=5)
 if args.scheme == "let":
-    sim = LetTreeSim(sp, args.theta, init, rank, world, local_rank, migrate_every=args.migrate_every)
+    sim = LetTreeSim(sp, args.theta, init, rank, world, local_rank, migrate_every=args.migrate_every,
+                     overlap=not args.no_overlap)
 else:
     sim = ShardedTreeSim(sp, args.theta, init, rank, world, local_rank, overlap=not args.no_overlap)
 for _ in range(args.warmup):

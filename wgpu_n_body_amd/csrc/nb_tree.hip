@@ -680,7 +680,11 @@ __device__ __forceinline__ void walk_cells(const NodeRec *__restrict__ rp, uint6
 // One wave walks for 64 consecutive sorted bodies, depth-first over sibling groups: a pop
 // pushes at most 8 groups one level down, so the stack holds at most 7 x 21 + 1 entries -- it
 // cannot overflow.
-template <bool COUNT>
+// PART: 0 = the whole step; 1 = walk the given trees and leave the raw sums in acc_dst (no
+// integration); 2 = start from those sums, walk the given trees, integrate.  1 then 2 add the same
+// terms in the same order as 0 does over the concatenated roots, so the result is bit-identical --
+// a LET host walks the rank's own tree (1) while the imported trees are still on the wire.
+template <bool COUNT, int PART = 0>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
@@ -706,6 +710,12 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
     float ax = 0.f, ay = 0.f, az = 0.f;
+    if (PART == 2 && valid) {
+        const float4 part = acc_dst[i];
+        ax = part.x;
+        ay = part.y;
+        az = part.z;
+    }
     const float theta2 = theta * theta;
     WalkStats st;
     const bool lane0 = lane == 0u;
@@ -756,16 +766,20 @@ __global__ __launch_bounds__(256) void walk_kernel(
         atomicAdd(&counters[4], (unsigned long long)st.wave_leaves);
         atomicMax(&counters[5], (unsigned long long)st.wave_cells);  // the longest walk of any wave
     }
+    if (COUNT && valid) {
+        atomicAdd(&counters[0], st.visits);
+        atomicAdd(&counters[1], st.accepts);
+    }
     if (!valid) return;
+    if (PART == 1) {
+        acc_dst[i] = float4{ax, ay, az, 0.f};
+        return;
+    }
     const float gdt = g * dt;
     const float fx = ax * gdt, fy = ay * gdt, fz = az * gdt;
     posm_dst[i] = float4{xi, yi, zi, p.w};
     vel_dst[i] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
     acc_dst[i] = float4{fx, fy, fz, 0.f};
-    if (COUNT) {
-        atomicAdd(&counters[0], st.visits);
-        atomicAdd(&counters[1], st.accepts);
-    }
 }
 
 // ---- 9. locally essential trees (multi-GPU Barnes-Hut) ------------------------
@@ -1187,6 +1201,7 @@ class TreeSim final : public SimBase {
     int encode_phase(int phase) override {
         if (int rc = bind_device()) return rc;
         if (phase == NB_PHASE_LET_MIGRATE) return let_migrate();
+        if (phase == NB_PHASE_LET_WALK_OWN) return let_walk_own();
         if (phase >= NB_PHASE_LET_META && phase <= NB_PHASE_LET_WALK) return let_phase(phase);
         if (phase != 0 && phase != 1) {
             set_error("encode_phase: phase must be 0 or 1 (or a NB_PHASE_LET_* value)");
@@ -1291,7 +1306,7 @@ class TreeSim final : public SimBase {
             return NB_ERR_INVALID;
         }
         WalkRoots roots{};
-        if (n) roots.id[roots.count++] = 0u;
+        if (n && !let_own_walked) roots.id[roots.count++] = 0u;
         const uint32_t total = let_segs.off[let_segs.world];
         if (total) {
             hipLaunchKernelGGL(let_rebase_kernel, dim3((total + 255) / 256), b256, 0, stream, rec + node_cap,
@@ -1300,10 +1315,28 @@ class TreeSim final : public SimBase {
                 if (let_segs.off[r + 1] > let_segs.off[r]) roots.id[roots.count++] = node_cap + let_segs.off[r];
         }
         if (n) {
-            if (int rc = enqueue_walk(roots)) return rc;
+            if (int rc = enqueue_walk(roots, let_own_walked ? 2 : 0)) return rc;
         }
+        let_own_walked = false;
         step_num += 1;
         let_next = NB_PHASE_LET_META;
+        return NB_OK;
+    }
+
+    // NB_PHASE_LET_WALK_OWN (optional, between BUILD and WALK): the rank's own tree needs nothing
+    // from the peers, so its part of the walk can run while the exported trees are exchanged;
+    // NB_PHASE_LET_WALK then adds the imported trees and integrates (same sums, same order).
+    int let_walk_own() {
+        if (!let_world || let_next != NB_PHASE_LET_WALK || let_own_walked) {
+            set_error("LET own-tree walk: only once, between NB_PHASE_LET_BUILD and NB_PHASE_LET_WALK");
+            return NB_ERR_INVALID;
+        }
+        if (n) {
+            WalkRoots roots{};
+            roots.id[roots.count++] = 0u;
+            if (int rc = enqueue_walk(roots, 1)) return rc;
+        }
+        let_own_walked = true;
         return NB_OK;
     }
 
@@ -1513,24 +1546,28 @@ class TreeSim final : public SimBase {
         return NB_OK;
     }
 
-    int enqueue_walk(const WalkRoots &roots) {
+    // part: 0 whole step, 1 own-tree sums only, 2 continue from those sums and integrate
+    int enqueue_walk(const WalkRoots &roots, int part = 0) {
         const int s = cur, d = cur ^ 1;
         uint32_t *status = scalars + 4;
         const dim3 b256(256);
-        hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
-                           vel[d], acc[d]);
+        if (part != 2)
+            hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
+                               vel[d], acc[d]);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
             const dim3 gwalk((hi - lo + 255) / 256);
-            if (count_visits)
-                hipLaunchKernelGGL(walk_kernel<true>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   roots, posm[s], vel[s], acc[s], lo, hi,
-                                   params.g, params.e, params.dt, theta, status, counters);
-            else
-                hipLaunchKernelGGL(walk_kernel<false>, gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,
-                                   roots, posm[s], vel[s], acc[s], lo, hi,
-                                   params.g, params.e, params.dt, theta, status, counters);
+#define NB_WALK(COUNT, PART)                                                                              \
+    hipLaunchKernelGGL((walk_kernel<COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,  \
+                       roots, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt, theta,      \
+                       status, counters)
+            if (count_visits) {
+                if (part == 0) NB_WALK(true, 0); else if (part == 1) NB_WALK(true, 1); else NB_WALK(true, 2);
+            } else {
+                if (part == 0) NB_WALK(false, 0); else if (part == 1) NB_WALK(false, 1); else NB_WALK(false, 2);
+            }
+#undef NB_WALK
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
         NB_HIP_TRY(hipGetLastError());
@@ -1772,7 +1809,7 @@ class TreeSim final : public SimBase {
     uint32_t *let_meta = nullptr, *let_counts = nullptr, *let_out_slot = nullptr;
     NodeRec *let_send = nullptr;
     LetSegments let_segs{};
-    bool let_imports_set = false, let_prune = true, let_arrivals_pending = false;
+    bool let_imports_set = false, let_prune = true, let_arrivals_pending = false, let_own_walked = false;
     uint32_t n_capacity = 0, let_mig_cap = 0;
     uint32_t *let_mig_counts = nullptr;
     float4 *let_mig_send = nullptr, *let_mig_recv = nullptr;

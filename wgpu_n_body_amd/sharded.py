@@ -357,11 +357,12 @@ class LetTreeSim:
     incoherent waves whose walks are ten times longer than the rest.  `rebalance()` (collective,
     host-side) re-cuts the domains from the current positions when the load has drifted."""
 
-    META, BUILD, WALK, MIGRATE = 2, 3, 4, 5
+    META, BUILD, WALK, MIGRATE, WALK_OWN = 2, 3, 4, 5, 6
     HEADROOM = 1.25     # body capacity of a rank relative to its start-up share
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
-                 device_index: int, group=None, let_cap: Optional[int] = None, migrate_every: int = 1):
+                 device_index: int, group=None, let_cap: Optional[int] = None, migrate_every: int = 1,
+                 overlap: bool = True):
         import torch
         self._torch = torch
         self.rank, self.world, self.group = rank, world, group
@@ -374,6 +375,10 @@ class LetTreeSim:
         self.step_num = 0
         self._let_cap = let_cap
         self.migrate_every = int(migrate_every)
+        # overlap: the rank's own tree is walked (NB_PHASE_LET_WALK_OWN) on the main stream while a
+        # side stream gathers the export counts, reads them and runs the all-to-all
+        self.overlap = bool(overlap)
+        self.side = torch.cuda.Stream(self._dev)
         self._adopt(as_particles(particles))
 
     # -- domain set-up -------------------------------------------------------------------------
@@ -430,7 +435,7 @@ class LetTreeSim:
         if dist.get_backend(self.group) == "nccl":
             dist.all_to_all(outs, ins, group=self.group)
             return recv_counts
-        self.stream.synchronize()
+        t.cuda.current_stream(self._dev).synchronize()
         host_in = [x.cpu() for x in ins]
         host_out = [t.empty(recv_counts[r] * R, dtype=t.float32) for r in range(W)]
         ops = []
@@ -476,8 +481,20 @@ class LetTreeSim:
             self.sim.encode_phase(self.META)
             self._all_gather(0)
             self.sim.encode_phase(self.BUILD)
-            counts = self._counts_matrix(1)
-            recv_counts = self._exchange_segments(counts, 2, 3, 8)
+            if self.overlap and self.world > 1:
+                built = t.cuda.Event()
+                built.record(self.stream)
+                self.sim.encode_phase(self.WALK_OWN)         # main stream: needs nothing from the peers
+                with t.cuda.stream(self.side):               # side stream: counts -> host -> all-to-all
+                    self.side.wait_event(built)
+                    counts = self._counts_matrix(1)
+                    recv_counts = self._exchange_segments(counts, 2, 3, 8)
+                    arrived = t.cuda.Event()
+                    arrived.record(self.side)
+                self.stream.wait_event(arrived)
+            else:
+                counts = self._counts_matrix(1)
+                recv_counts = self._exchange_segments(counts, 2, 3, 8)
             self.last_counts = counts
             self.sim.let_set_imports(recv_counts)
             self.sim.encode_phase(self.WALK)
