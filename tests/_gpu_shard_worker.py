@@ -26,10 +26,11 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     sp = nb.SimParams(particle_num=n)
-    if mode == "let":
+    rank_mode = mode
+    if mode in ("let", "let-overlap"):
         init = nb.inits.uniform_init(sp, seed=27).copy()   # = tests/test_let_gpu.py::tagged(nb, n, 27)
         nb.as_floats(init)[:, 9] = 1.0 + np.arange(n, dtype=np.float32) / np.float32(2 * n)
-        sim = LetTreeSim(sp, 0.5, init, rank, world, 0)
+        sim = LetTreeSim(sp, 0.5, init, rank, world, 0, overlap=(rank_mode == "let-overlap"))
         for _ in range(steps):
             sim.encode()
             sim.cleanup()

@@ -335,8 +335,8 @@ def test_let_migration_keeps_the_waves_coherent(gpu):
     assert longest[1] < 0.5 * longest[0], longest
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap")])
+def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     """The product class (LetTreeSim: torch.distributed for the three exchanges) as `world`
     processes on this one GPU, gloo standing in for RCCL == the in-process emulation above."""
     import socket
@@ -353,7 +353,7 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
-             str(n), str(steps), "let"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+             str(n), str(steps), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o

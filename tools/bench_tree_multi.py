@@ -21,7 +21,8 @@ ap.add_argument("--bodies", type=int, default=4194304)
 ap.add_argument("--theta", type=float, default=0.5)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
-ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--no-overlap", action="store_true", help="replicated scheme: no pipelining")
+ap.add_argument("--let-overlap", action="store_true", help="LET scheme: own-tree walk beside the exchange")
 ap.add_argument("--scheme", choices=("let", "replicated"), default="let")
 ap.add_argument("--migrate-every", type=int, default=1)
 args = ap.parse_args()
@@ -56,7 +57,7 @@ sp = nb.SimParams(particle_num=args.bodies)
 init = nb.inits.uniform_init(sp, seed=5)
 if args.scheme == "let":
     sim = LetTreeSim(sp, args.theta, init, rank, world, local_rank, migrate_every=args.migrate_every,
-                     overlap=not args.no_overlap)
+                     overlap=args.let_overlap)
 else:
     sim = ShardedTreeSim(sp, args.theta, init, rank, world, local_rank, overlap=not args.no_overlap)
 for _ in range(args.warmup):
@@ -80,7 +81,7 @@ if rank == 0:
                       "bodies": args.bodies, "theta": args.theta, "n_gpus": world,
                       "ms_per_step": wall / args.steps * 1e3,
                       "bodies_per_s": args.bodies * args.steps / wall,
-                      "overlap": not args.no_overlap, "steps": args.steps, "warmup": args.warmup}))
+                      "overlap": (args.let_overlap if args.scheme == "let" else not args.no_overlap), "steps": args.steps, "warmup": args.warmup}))
 sim.destroy()
 if world > 1:
     dist.barrier()

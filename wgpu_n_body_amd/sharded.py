@@ -269,6 +269,14 @@ class ShardedTreeSim:
         self.sim.destroy()
 
 
+_TRACE = bool(__import__("os").environ.get("NB_LET_TRACE"))
+
+
+def _now() -> float:
+    import time
+    return time.perf_counter()
+
+
 def _morton_keys(particles: np.ndarray) -> np.ndarray:
     """63-bit Morton keys of the positions quantised to 21 bits per axis in the cube
     [-bound, bound]^3, bound = max |coordinate| (as a float32, the value the device is given):
@@ -362,7 +370,7 @@ class LetTreeSim:
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
                  device_index: int, group=None, let_cap: Optional[int] = None, migrate_every: int = 1,
-                 overlap: bool = True):
+                 overlap: bool = False):
         import torch
         self._torch = torch
         self.rank, self.world, self.group = rank, world, group
@@ -376,9 +384,14 @@ class LetTreeSim:
         self._let_cap = let_cap
         self.migrate_every = int(migrate_every)
         # overlap: the rank's own tree is walked (NB_PHASE_LET_WALK_OWN) on the main stream while a
-        # side stream gathers the export counts, reads them and runs the all-to-all
+        # high-priority side stream gathers the export counts, reads them and runs the all-to-all.
+        # Bit-identical to the plain order.  Off by default: the walk keeps every wave slot of
+        # the GPU occupied (8 per SIMD), and up to 524,288 bodies per rank ALL its workgroups are
+        # resident at once, so the collective's kernels only get a CU when the walk drains --
+        # nothing is hidden until a rank holds more bodies than that (and two gloo ranks sharing
+        # one GPU, the only rehearsal available here, run slower with it).
         self.overlap = bool(overlap)
-        self.side = torch.cuda.Stream(self._dev)
+        self.side = torch.cuda.Stream(self._dev, priority=-1)   # its small kernels must not queue behind the walk
         self._adopt(as_particles(particles))
 
     # -- domain set-up -------------------------------------------------------------------------
@@ -487,14 +500,23 @@ class LetTreeSim:
                 self.sim.encode_phase(self.WALK_OWN)         # main stream: needs nothing from the peers
                 with t.cuda.stream(self.side):               # side stream: counts -> host -> all-to-all
                     self.side.wait_event(built)
+                    _t0 = _now()
                     counts = self._counts_matrix(1)
+                    _t1 = _now()
                     recv_counts = self._exchange_segments(counts, 2, 3, 8)
+                    _t2 = _now()
                     arrived = t.cuda.Event()
                     arrived.record(self.side)
                 self.stream.wait_event(arrived)
             else:
+                _t0 = _now()
                 counts = self._counts_matrix(1)
+                _t1 = _now()
                 recv_counts = self._exchange_segments(counts, 2, 3, 8)
+                _t2 = _now()
+            if _TRACE:
+                print(f"[let rank {self.rank} step {self.step_num}] counts {(_t1 - _t0) * 1e3:.2f} ms, "
+                      f"exchange {(_t2 - _t1) * 1e3:.2f} ms", flush=True)
             self.last_counts = counts
             self.sim.let_set_imports(recv_counts)
             self.sim.encode_phase(self.WALK)
