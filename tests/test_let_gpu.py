@@ -284,6 +284,23 @@ def test_let_own_tree_first_is_the_same_step(gpu):
     split.destroy()
 
 
+@pytest.mark.parametrize("n,world", [(5, 4), (2, 4), (1, 3), (64, 8)])
+def test_let_with_almost_empty_ranks(gpu, oracle, n, world):
+    """Fewer bodies than ranks: some domains hold one body or none; theta -> 0 must still be all-pairs."""
+    nb = gpu
+    sp, p = moving(nb, n, 34, 0.5)
+    grp = LetGroup(nb, sp, p, world, 1e-4, migrate_every=1)
+    for _ in range(3):
+        grp.step()
+    got = by_tag(nb, grp.particles())
+    want = oracle.naive_run_f64(nb.as_floats(p), sp.g, sp.e, sp.dt, 3)
+    want = want[np.argsort(want[:, 9], kind="stable")]
+    assert len(got) == n
+    assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 2e-6
+    assert np.abs(got[:, 6:9] - want[:, 6:9]).max() <= 2e-5 * max(np.abs(want[:, 6:9]).max(), 1e-30)
+    grp.destroy()
+
+
 def moving(nb, n, seed, speed):
     """tagged() bodies with random velocities, so that some cross domain borders in a few steps"""
     sp, p = tagged(nb, n, seed)
