@@ -196,8 +196,8 @@ class ShardedTreeSim:
     first, the NEXT step's sort + tree build is enqueued as soon as they have landed, and the
     velocity/acceleration gathers run beside it; only the walk waits for them.
 
-    The tree build itself is not sped up by more GPUs -- the spatial domain decomposition +
-    LET exchange of the north star is the next step."""
+    The tree build itself is not sped up by more GPUs and the whole state crosses the links
+    every step: LetTreeSim below (spatial domains + LET exchange) is the scheme that scales."""
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
                  device_index: int, group=None, overlap: bool = True):
