@@ -27,11 +27,13 @@ def main():
     torch.cuda.set_device(0)
     sp = nb.SimParams(particle_num=n)
     rank_mode = mode
-    if mode in ("let", "let-overlap"):
+    if mode in ("let", "let-overlap", "let-rebalance"):
         init = nb.inits.uniform_init(sp, seed=27).copy()   # = tests/test_let_gpu.py::tagged(nb, n, 27)
         nb.as_floats(init)[:, 9] = 1.0 + np.arange(n, dtype=np.float32) / np.float32(2 * n)
         sim = LetTreeSim(sp, 0.5, init, rank, world, 0, overlap=(rank_mode == "let-overlap"))
-        for _ in range(steps):
+        for k in range(steps):
+            if mode == "let-rebalance" and k == 2:
+                sim.rebalance()
             sim.encode()
             sim.cleanup()
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), nb.as_floats(sim.read_local()))

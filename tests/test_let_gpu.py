@@ -55,9 +55,19 @@ class LetGroup:
 
     def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0,
                  own_first=False):
-        from wgpu_n_body_amd.sharded import morton_domains
         self.nb, self.world, self.hip = nb, world, _hip()
         self.migrate_every, self.steps_done, self.own_first = migrate_every, 0, own_first
+        self.sp, self.theta, self.prune, self.cap = sp, theta, prune, cap
+        self.sims = []
+        self.counts = None
+        self.migrated = 0
+        self._adopt(particles)
+
+    def _adopt(self, particles):
+        from wgpu_n_body_amd.sharded import morton_domains
+        nb, world, sp, theta, prune, cap = self.nb, self.world, self.sp, self.theta, self.prune, self.cap
+        for s in self.sims:
+            s.destroy()
         order, cuts, splits, ref_bound = morton_domains(particles, world, with_owners=True)
         counts = [cuts[r + 1] - cuts[r] for r in range(world)]
         capacity = int(1.25 * max(counts)) + 4096
@@ -76,8 +86,10 @@ class LetGroup:
             s.set_tuning("tree_let_cap", cap or (2 * capacity + 64))
             s.let_set_owners(splits, ref_bound, self.mig_cap)
             self.sims.append(s)
-        self.counts = None
-        self.migrated = 0
+
+    def rebalance(self):
+        """what LetTreeSim.rebalance does: all bodies, rank by rank, re-cut into new domains"""
+        self._adopt(self.particles().copy())
 
     def _copy(self, dst, src, nbytes):
         if nbytes:
@@ -352,7 +364,7 @@ def test_let_migration_keeps_the_waves_coherent(gpu):
     assert longest[1] < 0.5 * longest[0], longest
 
 
-@pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap")])
+@pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap"), (3, "let-rebalance")])
 def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     """The product class (LetTreeSim: torch.distributed for the three exchanges) as `world`
     processes on this one GPU, gloo standing in for RCCL == the in-process emulation above."""
@@ -376,7 +388,9 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
         assert p.returncode == 0, o
     sp, p0 = tagged(nb, n, 27)
     grp = LetGroup(nb, sp, p0, world, theta, migrate_every=1)   # LetTreeSim's default schedule
-    for _ in range(steps):
+    for k in range(steps):
+        if mode == "let-rebalance" and k == 2:
+            grp.rebalance()
         grp.step()
     want = by_tag(nb, grp.particles())
     grp.destroy()
