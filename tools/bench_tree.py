@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--init", default="uniform")
 ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--bpw", type=int, default=None, help="bodies per wave of the walk (default: automatic)")
 ap.add_argument("--cpu-baseline", action="store_true",
                 help="also time the CPU oracle: the reference's serial BFS build + DFS reorder "
                      "(src/sims/tree.rs:417-602, single thread as in the reference) and the "
@@ -32,6 +33,8 @@ sim.set_tuning("tree_count_visits", 1)
 sim.encode(); sim.wait()
 c0 = sim.debug_buffer("counters", np.uint64).copy()
 sim.set_tuning("tree_count_visits", 0)
+if args.bpw is not None:
+    sim.set_tuning("tree_walk_bpw", args.bpw)
 for _ in range(args.warmup):
     sim.encode()
 sim.wait()

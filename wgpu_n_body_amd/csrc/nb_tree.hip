@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
     WalkRoots roots,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
-    uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
+    uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -721,8 +721,11 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t blk = blockIdx.x;
     if (blk < per_xcd * 8u) blk = (blk & 7u) * per_xcd + (blk >> 3);   // bijective on [0, 8*per_xcd)
                                                                        // the last < 8 blocks stay put
-    const uint32_t i = lo + blk * blockDim.x + threadIdx.x;
-    const bool valid = i < hi;
+    // A wave walks for 2^bpw_shift consecutive bodies (64 on large problems; fewer when there are
+    // not enough bodies to fill the chip: a small problem is bound by the LENGTH of one wave's
+    // walk, and the union of the cells of 8 bodies is much shorter than that of 64).
+    const uint32_t i = lo + ((blk * 4u + wave) << bpw_shift) + lane;
+    const bool valid = i < hi && lane < (1u << bpw_shift);
     const uint32_t ic = valid ? i : hi - 1;
     const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
@@ -1581,11 +1584,19 @@ class TreeSim final : public SimBase {
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo) {
-            const dim3 gwalk((hi - lo + 255) / 256);
+            // bodies per wave: 64 when that still gives >= 4096 waves (4 per SIMD), else halve down to 8
+            uint32_t shift = 6;
+            if (walk_bpw) {
+                shift = walk_bpw >= 64 ? 6 : walk_bpw >= 32 ? 5 : walk_bpw >= 16 ? 4 : 3;
+            } else {
+                while (shift > 3 && ((hi - lo) >> shift) < 4096u) --shift;
+            }
+            const uint32_t per_block = 4u << shift;
+            const dim3 gwalk((hi - lo + per_block - 1) / per_block);
 #define NB_WALK(COUNT, PART)                                                                              \
     hipLaunchKernelGGL((walk_kernel<COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,  \
-                       roots, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt, theta,      \
-                       status, counters)
+                       roots, posm[s], vel[s], acc[s], lo, hi, shift, params.g, params.e, params.dt,      \
+                       theta, status, counters)
             if (count_visits) {
                 if (part == 0) NB_WALK(true, 0); else if (part == 1) NB_WALK(true, 1); else NB_WALK(true, 2);
             } else {
@@ -1742,6 +1753,11 @@ class TreeSim final : public SimBase {
             drop_graph();  // a different walk kernel: re-capture
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_walk_bpw") == 0) {  // bodies per wave: 0 = automatic, else 8/16/32/64
+            walk_bpw = value < 0 ? 0 : (uint32_t)value;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_use_graph") == 0) {
             use_graph = value != 0;
             drop_graph();
@@ -1826,6 +1842,7 @@ class TreeSim final : public SimBase {
     unsigned long long *counters = nullptr;
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false, use_graph = false;
+    uint32_t walk_bpw = 0;
     bool build_done = false;  // phase 0 of the next step already enqueued
     // locally essential trees (section 9); let_world == 0: not in use
     int let_world = 0, let_rank = 0, let_next = 0;
