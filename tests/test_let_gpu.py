@@ -357,6 +357,7 @@ def test_let_migration_keeps_the_waves_coherent(gpu):
         grp = LetGroup(nb, sp, p, world, 0.5, migrate_every=every)
         for s in grp.sims:
             s.set_tuning("tree_count_visits", 1)
+            s.set_tuning("tree_walk_bpw", 64)     # full waves, as on a large problem
         for _ in range(steps):
             grp.step()
         longest[every] = max(int(s.debug_buffer("counters", np.uint64)[5]) for s in grp.sims)
