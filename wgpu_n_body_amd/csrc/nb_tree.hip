@@ -230,23 +230,57 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         local[c] = before + rank;
     }
     __syncthreads();
-    {   // per digit: exclusive prefix over the 4 waves
+    uint32_t tile_count;
+    {   // per digit: exclusive prefix over the 4 waves, and the digit's count in this tile
         uint32_t o = 0;
         for (uint32_t w = 0; w < 4; ++w) {
             const uint32_t t = s_cnt[w][threadIdx.x];
             s_cnt[w][threadIdx.x] = o;
             o += t;
         }
+        tile_count = o;
+    }
+    // exclusive scan of the tile's digit counts: where each digit's run starts inside the tile
+    __shared__ uint32_t s_tile[256], s_w2[4];
+    {
+        uint32_t x = tile_count;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) s_w2[wave] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wave; ++w) off += s_w2[w];
+        s_tile[threadIdx.x] = off + x - tile_count;
     }
     __syncthreads();
+    // Stage the tile in LDS in digit order, then write it out with consecutive threads on
+    // consecutive elements: each digit's run lands in global memory as one contiguous, coalesced
+    // stream instead of 64 scattered 8-byte stores per wave instruction.
+    __shared__ uint64_t s_key[kSortTile];
+    __shared__ uint32_t s_val[kSortTile];
 #pragma unroll
     for (uint32_t c = 0; c < kSortItems; ++c) {
         const uint32_t i = base + c * 64 + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-            const uint32_t dst = s_base[d] + s_cnt[wave][d] + local[c];
-            keys_out[dst] = key[c];
-            vals_out[dst] = val[c];
+            const uint32_t pos = s_tile[d] + s_cnt[wave][d] + local[c];
+            s_key[pos] = key[c];
+            s_val[pos] = val[c];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_n = min(kSortTile, n - blockIdx.x * kSortTile);
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t j = c * kSortThreads + threadIdx.x;
+        if (j < tile_n) {
+            const uint64_t k = s_key[j];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t dst = s_base[d] + (j - s_tile[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_val[j];
         }
     }
 }
