@@ -575,6 +575,10 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t *keys, uint32
     return lo;
 }
 
+// AOS = false (every step): only the 32-byte walk records.  AOS = true (nb_sim_read_tree, on
+// demand): also the reference's Octant fields -- cog, body count, the 8-entry children table
+// indexed by octant -- which cost two more dependent loads per child and 52 B of stores per node.
+template <bool AOS>
 __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint32_t n_cap,
                             const uint32_t *__restrict__ n_nodes_p,
                             const uint32_t *__restrict__ node_first,
@@ -594,9 +598,11 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
         const float4 p = posm[k];
-        cogm[id] = p;
-        bodies[id] = 1;
-        ch[0] = order[k];  // tree.rs:532
+        if (AOS) {
+            cogm[id] = p;
+            bodies[id] = 1;
+            ch[0] = order[k];  // tree.rs:532
+        }
         rec[id] = NodeRec{p, 0u, 0u, k, -1.0f};  // walk: a leaf knows its body's sorted position
     } else {
         const uint32_t d = dd;
@@ -612,7 +618,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             }
             end = lower_bound_key(keys, lo_s, min(k + off, n), limit);
         }
-        bodies[id] = end - k;
+        if (AOS) bodies[id] = end - k;
         // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
         // (nodes of one depth are numbered in key order), starting with body k's own child
         const int left = cpl[k], right = cpl[k + 1];
@@ -624,24 +630,24 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             f = leaf_id[k];
         }
         const uint32_t lim = min(depth_base[d + 2], n_nodes);  // end of the depth-(d+1) ids
+        uint32_t first = 0, cnt = 0;
         for (uint32_t j = 0; j < 8u; ++j) {
             const uint32_t cid = f + j;
             if (f == ~0u || cid >= lim) break;
             const uint32_t kc = node_first[cid];
             if (j > 0 && kc >= end) break;
-            ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+            if (AOS) ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+            if (cnt == 0u) first = cid;
+            ++cnt;
         }
         // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
         const Moments a = mom[k], b2 = mom[end];
         const double m = b2.m - a.m;
         const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
                                 (float)((b2.z - a.z) / m), (float)m};
-        cogm[id] = q;
+        if (AOS) cogm[id] = q;
         // children are allocated contiguously in octant order (tree.rs:517-519), so the walk
         // only needs the first child's id and how many there are
-        uint32_t first = 0, cnt = 0;
-        for (int c = 7; c >= 0; --c)
-            if (ch[c]) { first = ch[c]; ++cnt; }
         // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
         // children were not all stored is walked as a single body of the cell's mass
         // ... and children always carry larger ids than their parent (breadth-first numbering), which
@@ -655,8 +661,10 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             rec[id] = NodeRec{q, first, cnt, ~0u, size2};
         }
     }
+    if (AOS) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
+        for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
+    }
 }
 
 // ---- 8. walk + integrate ------------------------------------------------------------------------
@@ -1600,7 +1608,8 @@ class TreeSim final : public SimBase {
         hipLaunchKernelGGL(moments_kernel, dim3(mom_blocks), b256, 0, stream, posm[d], n,
                            (Moments *)nullptr, mom_offsets, mom_prefix);
         const uint32_t gnodes = (node_cap + 255) / 256;
-        hipLaunchKernelGGL(fill_kernel, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
+        sorted_keys = skeys;
+        hipLaunchKernelGGL(fill_kernel<false>, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
                            mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
         NB_HIP_TRY(hipGetLastError());
@@ -1695,6 +1704,12 @@ class TreeSim final : public SimBase {
         if (n_nodes_out) *n_nodes_out = nodes;
         const size_t m = std::min<size_t>(nodes, cap);
         if (m && dst) {
+            // the Octant fields are produced on demand from the step's build arrays, which stay
+            // intact until the next step (buffer cur^1 holds the sorted source the tree was built on)
+            hipLaunchKernelGGL(fill_kernel<true>, dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
+                               n, node_cap, scalars + 1, node_first, node_depth, cpl, int_slot, leaf_id, int_id,
+                               order, posm[cur ^ 1], mom_prefix, scalars + 16, scalars + 0, cogm, bodies, child,
+                               rec);
             hipLaunchKernelGGL(tree_to_aos_kernel, dim3((nodes + 255) / 256), dim3(256), 0, stream, cogm,
                                bodies, child, nodes, d_tree_aos);
             NB_HIP_TRY(hipMemcpyAsync(dst, d_tree_aos, sizeof(nb_octant) * m, hipMemcpyDeviceToHost, stream));
@@ -1862,6 +1877,7 @@ class TreeSim final : public SimBase {
     float4 *posm[2] = {nullptr, nullptr}, *vel[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr};
     uint64_t *keys[2] = {nullptr, nullptr};
     uint32_t *idx[2] = {nullptr, nullptr}, *order = nullptr;
+    uint64_t *sorted_keys = nullptr;  // of the last build
     nb_particle *d_aos = nullptr;
     nb_octant *d_tree_aos = nullptr;
     uint32_t *hist = nullptr, *totals = nullptr, *nint = nullptr, *int_slot = nullptr;
