@@ -64,3 +64,37 @@ def test_shard_plan_ranges(nb):
         edges = [plan.range(r) for r in range(world)]
         assert edges[0][0] == 0 and edges[-1][1] == n
         assert all(a[1] == b[0] or b[0] == n for a, b in zip(edges, edges[1:]))
+
+
+@pytest.mark.parametrize("world,R", [(2, 8), (3, 12), (4, 8)])
+def test_let_exchange_packs_every_peers_segment_in_rank_order(tmp_path, world, R):
+    """The all-to-all-v of the LET protocol (exchange_segments) with gloo on CPU tensors: rank q
+    must end up with counts[r][q] records of every rank r's segment q, packed in rank order,
+    and nothing else touched; the counts matrix itself is all-gathered in place row by row."""
+    port = free_port()
+    seg_records = 8
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "_gloo_let_worker.py"), str(tmp_path),
+             str(seg_records), str(R)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out.decode(errors="replace")[-2000:]
+    from tests._gloo_let_worker import counts_for
+    want = counts_for(world)
+    for me in range(world):
+        r = np.load(os.path.join(tmp_path, f"let_rank{me}.npz"))
+        assert np.array_equal(r["counts"], want)                  # the in-place all-gather of the rows
+        assert r["got"].tolist() == [0 if src == me else int(want[src, me]) for src in range(world)]
+        expect = []
+        for src in range(world):
+            if src == me:
+                continue
+            for k in range(int(want[src, me])):
+                expect += [src * 1000 + me * 100 + k * 10 + e for e in range(R)]
+        recv = r["recv"]
+        assert recv[:len(expect)].tolist() == [float(v) for v in expect]
+        assert (recv[len(expect):] == -2.0).all()                 # nothing written past the packed records

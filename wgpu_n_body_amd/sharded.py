@@ -342,6 +342,48 @@ def morton_domains(particles: np.ndarray, world: int, slack: float = 0.02, with_
     return order, cuts, splits, max(float(np.abs(pos).max()), 1e-30)
 
 
+def exchange_segments(send, seg: int, recv, counts: np.ndarray, me: int, world: int, R: int, group=None,
+                      sync=None) -> list:
+    """The all-to-all-v of the LET protocol.  `send` holds `world` segments of `seg` elements;
+    counts[r][q] records of R elements each go from rank r to rank q.  Moves counts[r][me]
+    records of every rank r's segment `me` into `recv`, packed in rank order (nothing for
+    r == me), and returns the per-rank record counts received.
+    RCCL: one grouped all-to-all on device views.  Other backends (gloo: the CPU tests and the
+    one-GPU rehearsal): point-to-point through host memory (`sync` first, if the data is the
+    product of enqueued device work)."""
+    import torch
+    import torch.distributed as dist
+    recv_counts = [0 if r == me else int(counts[r, me]) for r in range(world)]
+    send_counts = [0 if q == me else int(counts[me, q]) for q in range(world)]
+    offs = np.concatenate([[0], np.cumsum(recv_counts)])
+    outs = [recv[int(offs[r]) * R:(int(offs[r]) + recv_counts[r]) * R] for r in range(world)]
+    ins = [send[q * seg:q * seg + send_counts[q] * R] for q in range(world)]
+    if world == 1:
+        return recv_counts
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(outs, ins, group=group)
+        return recv_counts
+    if sync is not None:
+        sync()
+    host_in = [x.cpu() for x in ins]
+    host_out = [torch.empty(recv_counts[r] * R, dtype=recv.dtype) for r in range(world)]
+    ops = []
+    for peer in range(world):
+        if peer == me:
+            continue
+        if send_counts[peer]:
+            ops.append(dist.P2POp(dist.isend, host_in[peer], peer, group=group))
+        if recv_counts[peer]:
+            ops.append(dist.P2POp(dist.irecv, host_out[peer], peer, group=group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for r in range(world):
+        if recv_counts[r]:
+            outs[r].copy_(host_out[r])
+    return recv_counts
+
+
 class LetTreeSim:
     """Barnes-Hut on several GPUs, SURVEY 8(e) step 2: Morton-range domains, local octrees and a
     locally-essential-tree (LET) exchange (nb_sim_encode_phase(NB_PHASE_LET_*), include/nbody.h).
@@ -430,42 +472,10 @@ class LetTreeSim:
             dist.all_gather_into_tensor(full, full[off:off + ln], group=self.group)
 
     def _exchange_segments(self, counts: np.ndarray, k_send: int, k_recv: int, R: int) -> list:
-        """Move counts[r][me] records (R floats each) of rank r's segment `me` of region k_send
-        into region k_recv, packed in rank order.  RCCL: one grouped all-to-all on device views.
-        Other backends (the gloo rehearsal): point-to-point through host memory."""
-        import torch.distributed as dist
-        t = self._torch
         send, _, seg = self._views[k_send]
         recv, _, _ = self._views[k_recv]
-        me, W = self.rank, self.world
-        recv_counts = [0 if r == me else int(counts[r, me]) for r in range(W)]
-        send_counts = [0 if q == me else int(counts[me, q]) for q in range(W)]
-        offs = np.concatenate([[0], np.cumsum(recv_counts)])
-        outs = [recv[offs[r] * R:(offs[r] + recv_counts[r]) * R] for r in range(W)]
-        ins = [send[q * seg:q * seg + send_counts[q] * R] for q in range(W)]
-        if W == 1:
-            return recv_counts
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_to_all(outs, ins, group=self.group)
-            return recv_counts
-        t.cuda.current_stream(self._dev).synchronize()
-        host_in = [x.cpu() for x in ins]
-        host_out = [t.empty(recv_counts[r] * R, dtype=t.float32) for r in range(W)]
-        ops = []
-        for peer in range(W):
-            if peer == me:
-                continue
-            if send_counts[peer]:
-                ops.append(dist.P2POp(dist.isend, host_in[peer], peer, group=self.group))
-            if recv_counts[peer]:
-                ops.append(dist.P2POp(dist.irecv, host_out[peer], peer, group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for r in range(W):
-            if recv_counts[r]:
-                outs[r].copy_(host_out[r])
-        return recv_counts
+        return exchange_segments(send, seg, recv, counts, self.rank, self.world, R, self.group,
+                                 sync=lambda: self._torch.cuda.current_stream(self._dev).synchronize())
 
     def _counts_matrix(self, k: int) -> np.ndarray:
         t = self._torch
