@@ -398,3 +398,32 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     got = np.concatenate([np.load(os.path.join(tmp_path, f"rank{r}.npy")) for r in range(world)])
     got = got[np.argsort(got[:, 9], kind="stable")]
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_energy_and_momentum_after_many_steps_track_all_pairs(gpu, oracle):
+    """North-star check 'positions / energies after N steps': 20 steps of the single octree and of
+    the 4-domain LET run against 20 steps of the fp64 all-pairs oracle, theta = 0.5: kinetic energy
+    and total momentum within the method's error, positions within 1e-5 of the box size."""
+    nb = gpu
+    n, steps, theta = 4096, 20, 0.5
+    sp, p = moving(nb, n, 35, 0.05)
+    want = oracle.naive_run_f64(nb.as_floats(p), sp.g, sp.e, sp.dt, steps)
+    want = want[np.argsort(want[:, 9], kind="stable")]
+    single = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(theta), p)
+    grp = LetGroup(nb, sp, p, 4, theta, migrate_every=1)
+    for _ in range(steps):
+        single.encode()
+        grp.step()
+    m = want[:, 9]
+    ke_want = 0.5 * (m * (want[:, 3:6] ** 2).sum(axis=1)).sum()
+    mom_want = (m[:, None] * want[:, 3:6]).sum(axis=0)
+    for name, got in (("single tree", by_tag(nb, single.dest_particle_slice())),
+                      ("LET x4", by_tag(nb, grp.particles()))):
+        got = got.astype(np.float64)
+        ke = 0.5 * (got[:, 9] * (got[:, 3:6] ** 2).sum(axis=1)).sum()
+        mom = (got[:, 9:10] * got[:, 3:6]).sum(axis=0)
+        assert abs(ke - ke_want) <= 1e-5 * ke_want, (name, ke, ke_want)
+        assert np.abs(mom - mom_want).max() <= 1e-5 * np.abs(m[:, None] * want[:, 3:6]).sum(), name
+        assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 2e-5, name
+    single.destroy()
+    grp.destroy()
