@@ -205,6 +205,10 @@ def main():
                          "hbm_peak_gbps": 8000.0,
                          "kernel": "nb::naive_step_kernel", "kernel_ms": ms_kernel,
                          "flop_per_pair": FLOP_PER_PAIR,
+                         # the instruction-issue ceiling of this force law on this chip (DESIGN.md
+                         # section 4: 12 packed + 4 transcendental issues per 2 pairs at the measured
+                         # 1.85 / 3.41 ns per wave-instruction and SIMD): 3.59e12 pairs/s
+                         "issue_ceiling_frac": (achieved * 1e12 / FLOP_PER_PAIR) / 3.59e12,
                          "note": "compute-bound on FP32 VALU issue; 157.3 TFLOP/s is both the "
                                  "vector and the f32-MFMA dense peak"},
         }
