@@ -70,6 +70,10 @@ def lib() -> C.CDLL:
                                         C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
                                         C.POINTER(C.c_int64), f32p, f32p, u32p, f32p, u64p]
         L.nbo_tree_step_f32.restype = C.c_int
+        L.nbo_tree_walk_indices.argtypes = [f32p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_float, u32p,
+                                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                            u32p, C.c_uint32, f32p, u64p]
+        L.nbo_tree_walk_indices.restype = C.c_int
         _lib = L
     return _lib
 
@@ -174,6 +178,31 @@ def tree_step_f32(state, g, e, dt, theta, flags=INTENDED, max_depth=64):
                 root_width=float(rw.value),
                 stats=dict(visits=int(stats[0]), accepted=int(stats[1]), high_water=int(stats[2]),
                            overflowed=int(stats[3]), bad_index=int(stats[4])))
+
+
+def tree_walk_indices(sorted_src, tree, root_width, g, e, dt, theta, indices, order=None, flags=INTENDED):
+    """Walk + integrate the sorted bodies `indices` of an already built tree (tree.wgsl:41-111 per
+    body) -> (rows[len(indices),10], stats).  order[k] = source index of sorted body k (the leaves
+    name their body by source index, tree.rs:532); None: sorted_src is in source order."""
+    src = _as_state(sorted_src)
+    n = src.shape[0]
+    t = np.ascontiguousarray(tree)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    out = np.zeros((len(idx), 10), dtype=np.float32)
+    stats = np.zeros(5, dtype=np.uint64)
+    f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    od = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+    lib().nbo_tree_walk_indices(src.ctypes.data_as(f32p), n, t.ctypes.data, len(t), np.float32(root_width),
+                                od.ctypes.data_as(u32p) if od is not None else None, np.float32(g),
+                                np.float32(e), np.float32(dt), np.float32(theta), flags,
+                                idx.ctypes.data_as(u32p), len(idx), out.ctypes.data_as(f32p),
+                                stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out, dict(visits=int(stats[0]), accepted=int(stats[1]), high_water=int(stats[2]),
+                     overflowed=int(stats[3]), bad_index=int(stats[4]))
+
+
+def tree_walk_window(sorted_src, tree, root_width, g, e, dt, theta, lo, hi, order=None, flags=INTENDED):
+    return tree_walk_indices(sorted_src, tree, root_width, g, e, dt, theta, np.arange(lo, hi), order, flags)
 
 
 def isa() -> str:

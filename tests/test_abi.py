@@ -70,6 +70,10 @@ def test_defaults_match_the_reference(nb):
 
 def test_version_and_variants(nb):
     assert nb.version().startswith("nbody_hip") and "gfx950" in nb.version()
+    # the library carries the hash of the sources it was built from: a stale .so shipped beside
+    # newer sources (the .so is git-ignored and travels with the snapshot) fails here
+    from wgpu_n_body_amd.build import source_hash
+    assert nb.version().endswith("src:" + source_hash()), (nb.version(), source_hash())
     v = nb.naive_variants()
     assert len(v) >= 4 and len(set(v)) == len(v)
 

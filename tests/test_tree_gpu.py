@@ -29,9 +29,11 @@ from tests.helpers import DT, E, G, GOLDEN, bits, make_state
 pytestmark = pytest.mark.gpu
 
 
-def run_tree(nb, state, theta, steps=1, g=G, e=E, dt=DT, count=True):
+def run_tree(nb, state, theta, steps=1, g=G, e=E, dt=DT, count=True, tuning=None):
     sp = nb.SimParams(particle_num=len(state), g=g, e=e, dt=dt)
     sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(theta), state)
+    for key, value in (tuning or {}).items():
+        sim.set_tuning(key, value)
     if count:
         sim.set_tuning("tree_count_visits", 1)
     for _ in range(steps):
@@ -114,6 +116,39 @@ def test_tree_and_step_against_oracle(gpu, oracle, kind, n, theta, g, dt):
     check_tree(r["tree"], r["root_width"], r["order"], ref["tree"], ref["root_width"], ref["order"])
     check_step(r["dst"], ref["dst"])
     assert abs(int(r["counters"][0]) - ref["stats"]["visits"]) <= max(2, 1e-5 * ref["stats"]["visits"])
+
+
+# every shape of the walk: cells across the lanes with 4 / 8 / 16 bodies per wave (mode 1, the
+# default is 8), and bodies across the lanes with 8 ... 64 bodies per wave (mode 0)
+WALK_SHAPES = [{"tree_walk_mode": 1, "tree_walk_group": 4}, {"tree_walk_mode": 1, "tree_walk_group": 8},
+               {"tree_walk_mode": 1, "tree_walk_group": 16},
+               {"tree_walk_mode": 0, "tree_walk_bpw": 8}, {"tree_walk_mode": 0, "tree_walk_bpw": 16},
+               {"tree_walk_mode": 0, "tree_walk_bpw": 32}, {"tree_walk_mode": 0, "tree_walk_bpw": 64}]
+
+
+@pytest.mark.parametrize("kind,n,theta,g,dt", [("uniform", 4096, 0.5, G, DT), ("spherical", 5003, 0.75, G, DT),
+                                               ("disc", 3000, 0.75, 0.00001, 0.0016), ("uniform", 67, 0.5, G, DT)])
+def test_every_walk_shape_against_oracle(gpu, oracle, kind, n, theta, g, dt):
+    """All lanes, masks and group sizes of both walk kernels against the oracle: forces within the
+    fp32 tolerances of check_step, visit / accept counts equal to the oracle's per-thread walk,
+    and the integer work (tree, order, positions) bit-identical across the shapes."""
+    s = make_state(kind, n, 900 + n, g)
+    ref = oracle.tree_step_f32(s, g, E, dt, theta, flags=oracle.INTENDED)
+    first = None
+    for shape in WALK_SHAPES:
+        r = run_tree(gpu, s, theta, 1, g, E, dt, tuning=shape)
+        assert not r["status"].any(), shape
+        check_step(r["dst"], ref["dst"])
+        assert abs(int(r["counters"][0]) - ref["stats"]["visits"]) <= max(2, 1e-5 * ref["stats"]["visits"]), shape
+        assert abs(int(r["counters"][1]) - ref["stats"]["accepted"]) <= max(2, 1e-5 * ref["stats"]["accepted"]), shape
+        if first is None:
+            first = r
+        else:
+            assert np.array_equal(r["order"], first["order"])
+            assert np.array_equal(bits(r["dst"][:, 0:3]), bits(first["dst"][:, 0:3]))
+            # the shapes add the same terms in different orders: fp32 rounding apart
+            scale = np.abs(first["dst"][:, 6:9]).max()
+            assert np.abs(r["dst"][:, 6:9] - first["dst"][:, 6:9]).max() <= 3e-6 * scale, shape
 
 
 def test_bodies_outside_the_unit_cube_scale_the_root(gpu, oracle):
@@ -213,6 +248,23 @@ def test_full_size_tree_invariants_and_sampled_walk(gpu, oracle):
     assert np.array_equal(ref_tree["bodies"], tree["bodies"])
     assert np.array_equal(ref_tree["children"], tree["children"])
     assert np.array_equal(oracle.tree_dfs_order(ref_tree, n), order)
+    # ... and the FORCES at this size (depth >= 10, ~1,000 cells per body, the XCD remap, full
+    # stacks): the oracle's per-thread walk (tree.wgsl:41-90, intended semantics) over windows of
+    # the sorted bodies at the start, in the middle and at the end, against the bit-identical tree
+    sorted_src = s[order]
+    for start in (0, n // 2 - 128, n - 256):
+        sel = np.arange(start, start + 256)
+        want, stats = oracle.tree_walk_window(sorted_src, ref_tree, ref_rw, G, E, DT, 0.5, start, start + 256, order)
+        got = r["dst"][sel]
+        assert np.array_equal(bits(got[:, 0:3]), bits(want[:, 0:3]))
+        err = rel_err(got[:, 6:9], want[:, 6:9])
+        assert np.median(err) < 1e-5 and np.percentile(err, 99) < 1e-4 and err.max() < 5e-2, (start, err.max())
+    # visit / accept totals of the whole problem against the oracle's walk of a 1/64 sample,
+    # scaled (the walk statistics are homogeneous on uniform data): within 2 %
+    sample = np.arange(0, n, 64)
+    _w, st = oracle.tree_walk_indices(sorted_src, ref_tree, ref_rw, G, E, DT, 0.5, sample, order)
+    assert abs(int(r["counters"][0]) / n - st["visits"] / len(sample)) < 0.02 * st["visits"] / len(sample)
+    assert abs(int(r["counters"][1]) / n - st["accepted"] / len(sample)) < 0.02 * st["accepted"] / len(sample)
 
 
 @pytest.mark.parametrize("n,world,mode", [(5000, 2, "tree"), (3000, 3, "tree-overlap"),
@@ -289,7 +341,8 @@ def test_many_fresh_tree_sims_are_consistent(gpu):
 def test_clustered_input_cannot_overflow_the_build(gpu):
     """Pairs of nearly coincident bodies open ~20 single-child cells each: far more internal
     cells than the reference's 4N-node capacity (tree.rs:188-190, where the reference panics).
-    The build must stay in bounds and report it through the status word / an error, not fault."""
+    The build must stay in bounds and report it -- from nb_sim_wait already (a caller that only
+    steps and never reads back must see it too), not fault."""
     nb = gpu
     n = 4096
     s = make_state("uniform", n, 77)
@@ -297,15 +350,35 @@ def test_clustered_input_cannot_overflow_the_build(gpu):
     sp = nb.SimParams(particle_num=n)
     sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), s)
     sim.encode()
-    sim.wait()
+    with pytest.raises(nb.NBodyError) as ei:
+        sim.wait()
+    assert "nodes" in str(ei.value) or "Morton key" in str(ei.value)
     status = sim.debug_buffer("status", np.uint32)
-    try:
-        tree, _ = sim.read_tree()
-        assert len(tree) <= 4 * n + 8
-    except nb.NBodyError as ex:
-        assert "nodes" in str(ex) or "stack" in str(ex) or "budget" in str(ex)
-        assert status.any()
+    assert status.any()
+    with pytest.raises(nb.NBodyError):
+        sim.read_tree()
     sim.destroy()
+
+
+def test_more_than_eight_bodies_on_one_key_are_reported(gpu):
+    """Twelve bodies inside one cell of the finest level (closer than root_width / 2^21): the
+    reference's build_tree recurses on them until its node buffer overflows (tree.rs:473-544);
+    here the step completes in bounds and every entry point that waits reports it -- the runner's
+    step, the timing loop and the read-back alike -- instead of silently dropping sources."""
+    nb = gpu
+    n = 2048
+    s = make_state("uniform", n, 78)
+    s[100:112, 0:3] = s[100, 0:3] + (np.arange(12, dtype=np.float32)[:, None] * np.float32(1e-9))
+    sp = nb.SimParams(particle_num=n)
+    runner = nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(0.5), lambda p: s)
+    with pytest.raises(nb.NBodyError) as ei:
+        runner.step()
+    assert "Morton key" in str(ei.value)
+    with pytest.raises(nb.NBodyError):
+        runner.sim.encode_n_timed(2)
+    with pytest.raises(nb.NBodyError):
+        runner.read_particles()
+    runner.destroy()
 
 
 def test_tree_step_in_two_phases(gpu):

@@ -20,6 +20,8 @@ ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--init", default="uniform")
 ap.add_argument("--seed", type=int, default=3)
 ap.add_argument("--bpw", type=int, default=None, help="bodies per wave of the walk (default: automatic)")
+ap.add_argument("--mode", type=int, default=None, help="walk kernel: 1 cells across the lanes (default), 0 bodies across the lanes")
+ap.add_argument("--group", type=int, default=None, help="bodies per wave of mode 1 (4/8/16)")
 ap.add_argument("--cpu-baseline", action="store_true",
                 help="also time the CPU oracle: the reference's serial BFS build + DFS reorder "
                      "(src/sims/tree.rs:417-602, single thread as in the reference) and the "
@@ -29,12 +31,16 @@ args = ap.parse_args()
 sp = nb.SimParams(particle_num=args.bodies)
 init = getattr(nb.inits, args.init + "_init")(sp, seed=args.seed)
 sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(args.theta), init)
+if args.mode is not None:
+    sim.set_tuning("tree_walk_mode", args.mode)
+if args.group is not None:
+    sim.set_tuning("tree_walk_group", args.group)
+if args.bpw is not None:
+    sim.set_tuning("tree_walk_bpw", args.bpw)
 sim.set_tuning("tree_count_visits", 1)
 sim.encode(); sim.wait()
 c0 = sim.debug_buffer("counters", np.uint64).copy()
 sim.set_tuning("tree_count_visits", 0)
-if args.bpw is not None:
-    sim.set_tuning("tree_walk_bpw", args.bpw)
 for _ in range(args.warmup):
     sim.encode()
 sim.wait()
@@ -73,4 +79,5 @@ print(json.dumps({
     "visits_per_body_step1": float(c0[0]) / args.bodies, "accepted_per_body_step1": float(c0[1]) / args.bodies,
     "lane_visits_per_s": float(c0[0]) / (walk * 1e-3),
     "cells_per_wave_step1": float(c0[2]) / ((args.bodies + 63) // 64), "stack_high_water": int(c0[3]), "leaf_fraction_of_wave_cells": float(c0[4]) / float(c0[2]) if c0[2] else None,
-    "lane_utilisation": float(c0[0]) / (64.0 * float(c0[2])) if c0[2] else None, "steps": args.steps, "warmup": args.warmup, "cpu_baseline": cpu}))
+    "lane_utilisation": (float(c0[0]) / float(c0[7]) if c0[7] else float(c0[0]) / (64.0 * float(c0[2]))) if c0[2] else None,
+    "batches_step1": int(c0[6]), "mode": args.mode, "group": args.group, "steps": args.steps, "warmup": args.warmup, "cpu_baseline": cpu}))

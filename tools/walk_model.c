@@ -1,0 +1,250 @@
+// walk_model.c -- CPU model of the wave-level union traversal of walk_kernel (nb_tree.hip), used to
+// size design choices before spending GPU time: for groups of G Morton-consecutive bodies it
+// replays the sibling-group walk with per-body acceptance tests (size^2 < theta^2 r^2) and reports,
+// per tree depth, the per-body visits, the cells the group evaluates (the union), the lane
+// utilisation, and the histogram of active-lane counts.  Builder tool only (not shipped, not a
+// test); the tree is a plain Morton octree on uniform random points, which has the same statistics
+// as the reference's tree on uniform_init data.
+//
+//   gcc -O2 -fopenmp -o /tmp/walk_model tools/walk_model.c -lm && /tmp/walk_model 1048576 0.5
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y, z, m; } f4;
+typedef struct { f4 cogm; uint32_t first, count, self_pos; float ssize2; int depth; } Rec;
+
+static uint64_t rng_state = 88172645463325252ull;
+static double urand(void) {
+    rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+    return (double)(rng_state >> 11) / 9007199254740992.0;
+}
+static uint64_t spread(uint64_t v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+typedef struct { uint64_t key; f4 p; } KP;
+static int cmp_kp(const void *a, const void *b) {
+    const uint64_t x = ((const KP *)a)->key, y = ((const KP *)b)->key;
+    return x < y ? -1 : x > y;
+}
+
+static KP *kp;
+static Rec *rec;
+static uint32_t n_nodes;
+
+// breadth-first build so that the children of a cell are consecutive (as in the product)
+typedef struct { uint32_t lo, hi, id; int depth; } Job;
+static void build(uint32_t n) {
+    Job *q = malloc(sizeof(Job) * 4 * (size_t)n);
+    uint32_t head = 0, tail = 0;
+    q[tail++] = (Job){0, n, 0, 0};
+    n_nodes = 1;
+    while (head < tail) {
+        const Job j = q[head++];
+        Rec *r = &rec[j.id];
+        r->depth = j.depth;
+        if (j.hi - j.lo == 1) {
+            r->cogm = kp[j.lo].p; r->first = 0; r->count = 0; r->self_pos = j.lo; r->ssize2 = -1.f;
+            continue;
+        }
+        double sx = 0, sy = 0, sz = 0, sm = 0;
+        for (uint32_t k = j.lo; k < j.hi; ++k) {
+            sx += kp[k].p.x * kp[k].p.m; sy += kp[k].p.y * kp[k].p.m; sz += kp[k].p.z * kp[k].p.m; sm += kp[k].p.m;
+        }
+        r->cogm = (f4){(float)(sx / sm), (float)(sy / sm), (float)(sz / sm), (float)sm};
+        const float w = 2.0f / (float)(1u << j.depth);
+        r->ssize2 = w * w; r->self_pos = ~0u; r->first = n_nodes; r->count = 0;
+        const int shift = 3 * (20 - j.depth);
+        uint32_t k = j.lo;
+        while (k < j.hi) {
+            const uint64_t d = (kp[k].key >> shift) & 7;
+            uint32_t e = k;
+            while (e < j.hi && ((kp[e].key >> shift) & 7) == d) ++e;
+            q[tail++] = (Job){k, e, n_nodes++, j.depth + 1};
+            r->count++;
+            k = e;
+        }
+    }
+    free(q);
+}
+
+#define MAXD 24
+typedef struct {
+    double visits[MAXD], cells[MAXD], accepts[MAXD], take0[MAXD], full[MAXD], groups, gcells;
+    double pop_hist[65];      // wave-cells by popcount of the group mask
+    double iter4[MAXD];       // ceil(gcnt / (64/G)) per popped group (scheme B iterations)
+    double sub16[MAXD];       // cells whose mask fits one aligned 16-lane quarter (G = 64 only)
+    double quarters[MAXD];    // sum over cells of the number of aligned 16-lane quarters the mask touches
+    double octs[MAXD];        // ... of aligned 8-lane octets
+} Stats;
+
+typedef struct { uint32_t first, count; uint64_t mask; } Ent;
+
+static void walk_group(uint32_t lo, int G, float theta2, Stats *st) {
+    static _Thread_local Ent stack[512];
+    int sp = 0;
+    const uint64_t all = G == 64 ? ~0ull : ((1ull << G) - 1);
+    stack[sp++] = (Ent){0, 1, all};
+    const int per = 64 / G;
+    while (sp > 0) {
+        const Ent t = stack[--sp];
+        st->groups += 1; st->gcells += t.count;
+        for (uint32_t c = 0; c < t.count; ++c) {
+            const Rec *r = &rec[t.first + c];
+            uint64_t far = 0, other = 0;
+            for (int l = 0; l < G; ++l) {
+                if (!((t.mask >> l) & 1)) continue;
+                const f4 p = kp[lo + l].p;
+                const float dx = r->cogm.x - p.x, dy = r->cogm.y - p.y, dz = r->cogm.z - p.z;
+                const float r2 = dz * dz + (dy * dy + dx * dx);
+                if (r->ssize2 < theta2 * r2) far |= 1ull << l;
+                if (r->self_pos != lo + l) other |= 1ull << l;
+            }
+            const uint64_t take = t.mask & far & other, open = t.mask & ~far;
+            const int d = r->depth, pc = __builtin_popcountll(t.mask);
+            st->visits[d] += pc; st->cells[d] += 1; st->accepts[d] += __builtin_popcountll(take);
+            if (!take) st->take0[d] += 1;
+            if (t.mask == all) st->full[d] += 1;
+            st->pop_hist[pc] += 1;
+            int nq = 0, no = 0;
+            for (int qd = 0; qd < 4; ++qd) if ((t.mask >> (16 * qd)) & 0xffff) ++nq;
+            for (int o = 0; o < 8; ++o) if ((t.mask >> (8 * o)) & 0xff) ++no;
+            st->quarters[d] += nq; st->octs[d] += no;
+            if (nq == 1) st->sub16[d] += 1;
+            if (open) stack[sp++] = (Ent){r->first, r->count, open};
+        }
+        st->iter4[rec[t.first].depth] += (t.count + per - 1) / per;
+    }
+}
+
+
+// ---- scheme C: cells across the 64 lanes, the group's G bodies in scalars -------------------------
+// LIFO stack of (cell, G-bit visit mask); a batch pops up to 64 cells, every lane tests its cell
+// against each of the G bodies, the children of opened cells are pushed (siblings contiguous).
+typedef struct { uint32_t id; uint32_t mask; } CEnt;
+typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any; } CStats;
+static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st) {
+    static _Thread_local CEnt stack[1 << 16];
+    int sp = 0, hw = 0;
+    stack[sp++] = (CEnt){0, (G == 32 ? 0xffffffffu : ((1u << G) - 1))};
+    while (sp > 0) {
+        const int c = sp < batch ? sp : batch;
+        CEnt cur[64];
+        memcpy(cur, stack + sp - c, sizeof(CEnt) * c);
+        sp -= c;
+        st->batches += 1; st->cells += c; st->pairs += (double)batch * G;
+        uint32_t any = 0;
+        for (int l = 0; l < c; ++l) {
+            const Rec *r = &rec[cur[l].id];
+            uint32_t open = 0;
+            any |= cur[l].mask;
+            for (int b = 0; b < G; ++b) {
+                if (!((cur[l].mask >> b) & 1)) continue;
+                const f4 p = kp[lo + b].p;
+                const float dx = r->cogm.x - p.x, dy = r->cogm.y - p.y, dz = r->cogm.z - p.z;
+                const float r2 = dz * dz + (dy * dy + dx * dx);
+                st->visits += 1;
+                if (!(r->ssize2 < theta2 * r2)) open |= 1u << b;
+            }
+            if (open)
+                for (uint32_t k = 0; k < r->count; ++k) stack[sp++] = (CEnt){r->first + k, open};
+        }
+        st->pairs_any += (double)batch * __builtin_popcount(any);
+        if (sp > hw) hw = sp;
+    }
+    st->hw += hw;
+    if (hw > st->maxhw) st->maxhw = hw;
+}
+
+int main(int argc, char **argv) {
+    const uint32_t n = argc > 1 ? (uint32_t)atol(argv[1]) : 1u << 20;
+    const float theta = argc > 2 ? (float)atof(argv[2]) : 0.5f;
+    const int sample = argc > 3 ? atoi(argv[3]) : 512;   // groups of 64 sampled
+    kp = malloc(sizeof(KP) * (size_t)n);
+    rec = malloc(sizeof(Rec) * 4 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float x = (float)(urand() * 2 - 1), y = (float)(urand() * 2 - 1), z = (float)(urand() * 2 - 1);
+        kp[i].p = (f4){x, y, z, 1.f};
+        const uint64_t qx = (uint64_t)((x + 1.0) * 0.5 * 2097152.0), qy = (uint64_t)((y + 1.0) * 0.5 * 2097152.0),
+                       qz = (uint64_t)((z + 1.0) * 0.5 * 2097152.0);
+        kp[i].key = spread(qx) | (spread(qy) << 1) | (spread(qz) << 2);
+    }
+    qsort(kp, n, sizeof(KP), cmp_kp);
+    build(n);
+    printf("n %u nodes %u (%.3f N) theta %.2f\n", n, n_nodes, (double)n_nodes / n, theta);
+    const int Gs[4] = {64, 32, 16, 8};
+    for (int gi = 0; gi < 4; ++gi) {
+        const int G = Gs[gi];
+        Stats tot; memset(&tot, 0, sizeof tot);
+        const uint32_t n64 = n / 64, stride = n64 / sample ? n64 / sample : 1;
+#pragma omp parallel
+        {
+            Stats st; memset(&st, 0, sizeof st);
+#pragma omp for schedule(dynamic, 4)
+            for (uint32_t w = 0; w < n64; w += stride)
+                for (int s = 0; s < 64 / G; ++s) walk_group(w * 64 + s * G, G, theta * theta, &st);
+#pragma omp critical
+            {
+                double *a = (double *)&tot, *b = (double *)&st;
+                for (size_t k = 0; k < sizeof(Stats) / sizeof(double); ++k) a[k] += b[k];
+            }
+        }
+        double V = 0, Cc = 0, A = 0, T0 = 0, F = 0, I4 = 0;
+        const double ngroups = (double)((n64 + stride - 1) / stride) * (64 / G);
+        printf("\nG = %d bodies per group (%g groups sampled)\n", G, ngroups);
+        printf(" depth  visits/body  cells/group  util   take0%%  fullmask%%  quarters/cell octets/cell iterB/group\n");
+        for (int d = 0; d < MAXD; ++d) {
+            if (!tot.cells[d]) continue;
+            printf(" %5d  %10.1f  %10.1f  %5.3f  %5.1f  %5.1f  %5.2f  %5.2f  %8.1f\n", d, tot.visits[d] / (ngroups * G), tot.cells[d] / ngroups,
+                   tot.visits[d] / (tot.cells[d] * G), 100 * tot.take0[d] / tot.cells[d], 100 * tot.full[d] / tot.cells[d],
+                   tot.quarters[d] / tot.cells[d], tot.octs[d] / tot.cells[d], tot.iter4[d] / ngroups);
+            V += tot.visits[d]; Cc += tot.cells[d]; A += tot.accepts[d]; T0 += tot.take0[d]; F += tot.full[d]; I4 += tot.iter4[d];
+        }
+        printf(" total  visits/body %.1f accepts/body %.1f cells/group %.1f util %.3f take0 %.1f%% full %.1f%% pops/group %.1f cells/pop %.2f iterB/group %.1f (x%d lanes-of-cells)\n",
+               V / (ngroups * G), A / (ngroups * G), Cc / ngroups, V / (Cc * G), 100 * T0 / Cc, 100 * F / Cc, tot.groups / ngroups,
+               tot.gcells / tot.groups, I4 / ngroups, 64 / G);
+        if (G == 64) {
+            double q = 0, o = 0;
+            for (int d = 0; d < MAXD; ++d) { q += tot.quarters[d]; o += tot.octs[d]; }
+            printf(" G=64: sum of touched 16-lane quarters per group %.1f (util if only touched quarters cost: %.3f); touched octets %.1f (util %.3f)\n",
+                   q / ngroups, V / (q * 16), o / ngroups, V / (o * 8));
+            printf(" popcount histogram (wave-cells %%): ");
+            double cum = 0;
+            for (int p = 1; p <= 64; ++p) { cum += tot.pop_hist[p]; if (p % 8 == 0) { printf("<=%d: %.1f  ", p, 100 * cum / Cc); } }
+            printf("\n");
+        }
+    }
+
+    printf("\nscheme C (cells across lanes, G bodies in scalars, LIFO stack, batch 64)\n");
+    const int Gc[4] = {4, 8, 16, 32};
+    for (int gi = 0; gi < 4; ++gi) {
+        const int G = Gc[gi];
+        CStats tot; memset(&tot, 0, sizeof tot);
+        const uint32_t n64 = n / 64, stride = n64 / sample ? n64 / sample : 1;
+#pragma omp parallel
+        {
+            CStats st; memset(&st, 0, sizeof st);
+#pragma omp for schedule(dynamic, 4)
+            for (uint32_t w = 0; w < n64; w += stride)
+                for (int s = 0; s < 64 / G; ++s) walk_group_c(w * 64 + s * G, G, theta * theta, 64, &st);
+#pragma omp critical
+            {
+                tot.batches += st.batches; tot.cells += st.cells; tot.pairs += st.pairs; tot.visits += st.visits;
+                tot.hw += st.hw; tot.pairs_any += st.pairs_any; if (st.maxhw > tot.maxhw) tot.maxhw = st.maxhw;
+            }
+        }
+        const double ngroups = (double)((n64 + stride - 1) / stride) * (64 / G);
+        printf(" G %2d: batches/group %.1f  cells/group %.1f  fill %.3f  pair-instr per 64 bodies %.0f  util %.3f  (skipping bodies absent from a batch: %.0f, util %.3f)  stack high water mean %.0f max %.0f\n",
+               G, tot.batches / ngroups, tot.cells / ngroups, tot.cells / (tot.batches * 64), tot.pairs / 64 / ngroups * (64 / G),
+               tot.visits / tot.pairs, tot.pairs_any / 64 / ngroups * (64 / G), tot.visits / tot.pairs_any, tot.hw / ngroups, tot.maxhw);
+    }
+    return 0;
+}

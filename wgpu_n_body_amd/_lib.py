@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnbody_hip.so")
+# NB_LIB: an alternative build of the same library (kernel tuning experiments); default in-tree
+LIB_PATH = os.environ.get("NB_LIB") or os.path.join(_PKG, "libnbody_hip.so")
 
 # `struct Particle`, src/sims/mod.rs:9-16 -- 40 bytes
 PARTICLE_DTYPE = np.dtype(

@@ -37,6 +37,20 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def source_hash() -> str:
+    """sha256 over every source the library is built from (sorted by name).  Compiled into the
+    library (nb_version() ends with "src:<12 hex digits>") so that a stale .so shipped beside newer
+    sources is caught by tests/test_abi.py and by __graft_entry__.build()."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                    if f.endswith((".hip", ".cpp", ".hpp"))] + [os.path.join(INCLUDE, "nbody.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _newer(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -52,11 +66,19 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     common = ["-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", "-Wall",
               "-Wno-unused-function"]
     objs = []
+    # the source hash goes into nb_abi.o; a changed hash (any source edited) recompiles it
+    digest = source_hash()
+    stamp = os.path.join(OBJ, "source_hash.txt")
+    stamp_ok = os.path.exists(stamp) and open(stamp).read().strip() == digest
+    if os.environ.get("NB_ALL_VARIANTS") == "1":
+        common.append("-DNB_ALL_VARIANTS")
     for src, extra in SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, [path] + hdrs):
+        if src == "nb_abi.cpp":
+            extra = extra + [f'-DNB_SOURCE_HASH="{digest}"']
+        if force or _newer(obj, [path] + hdrs) or (src == "nb_abi.cpp" and not stamp_ok):
             cmd = [hipcc, f"--offload-arch={ARCH}"] + common + extra + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
@@ -66,6 +88,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     # the C++ host mirror (simulator.hpp) + the headless CLI, plain g++ against the C ABI
     cli_src = os.path.join(CSRC, "headless.cpp")
     if force or _newer(HEADLESS, [cli_src, os.path.join(CSRC, "simulator.hpp"), LIB]):

@@ -389,7 +389,12 @@ using namespace nb;
 extern "C" {
 
 const char *nb_last_error(void) { return g_last_error.c_str(); }
-const char *nb_version(void) { return "nbody_hip 0.1.0 gfx950"; }
+#ifndef NB_SOURCE_HASH
+#define NB_SOURCE_HASH "unknown"
+#endif
+// "... src:<hash>": sha256 prefix of the sources this binary was built from (build.py), so that a
+// stale library next to newer sources is detectable (tests/test_abi.py)
+const char *nb_version(void) { return "nbody_hip 0.2.0 gfx950 src:" NB_SOURCE_HASH; }
 
 int nb_device_count(void) {
     int c = 0;

@@ -343,45 +343,34 @@ struct Variant {
 };
 #define NB_V(IB, W, SRC, PK, UN) \
     { "ib" #IB "_w" #W "_" #SRC "_pk" #PK "_u" #UN, naive_step_kernel<IB, W, SRC, PK, UN>, IB, W }
+// The shipped table holds the shapes that win somewhere (profiles/r01_variant_sweep.txt); the full
+// sweep of round 1 (29 shapes, ~1 min of hipcc) is compiled only with -DNB_ALL_VARIANTS
+// (tools/variant_sweep.py builds it on demand).
 const Variant kVariants[] = {
-    NB_V(2, 8, kLds, false, 8),   // 0: default until measured otherwise
-    NB_V(2, 8, kLds, true, 8),    // 1
-    NB_V(2, 8, kSmem, false, 8),  // 2
-    NB_V(2, 8, kSmem, true, 8),   // 3
-    NB_V(2, 4, kLds, false, 8),   // 4
-    NB_V(2, 4, kLds, true, 8),    // 5
-    NB_V(4, 8, kLds, false, 4),   // 6
-    NB_V(4, 8, kLds, true, 4),    // 7
-    NB_V(4, 4, kLds, true, 4),    // 8
-    NB_V(1, 8, kLds, false, 8),   // 9
-    NB_V(1, 16, kLds, false, 8),  // 10
-    NB_V(2, 16, kLds, false, 8),  // 11
-    NB_V(2, 16, kLds, true, 8),   // 12
-    NB_V(4, 8, kSmem, true, 4),   // 13
-    NB_V(4, 16, kLds, true, 2),   // 14
-    NB_V(4, 8, kLds, true, 2),    // 15
-    NB_V(4, 16, kSmem, true, 2),  // 16
-    NB_V(2, 16, kSmem, true, 8),  // 17
-    NB_V(2, 16, kLds, true, 4),   // 18
-    NB_V(4, 16, kLds, true, 1),   // 19
-    NB_V(4, 16, kLds, true, 4),   // 20
-    NB_V(8, 16, kLds, true, 1),   // 21
-    NB_V(8, 8, kLds, true, 1),    // 22
-    NB_V(4, 16, kLds, true, 8),   // 23
-    NB_V(4, 8, kLds, true, 8),    // 24
-    NB_V(2, 16, kLds, true, 16),  // 25
-    NB_V(4, 16, kSmem, true, 4),  // 26
-    NB_V(2, 16, kSmem, true, 16), // 27
-    NB_V(2, 16, kSmem, true, 4),  // 28
+    NB_V(2, 8, kLds, false, 8),   // 0: unpacked baseline (2 bodies per lane, 8 waves)
+    NB_V(2, 8, kLds, true, 8),    // 1: the same, packed fp32
+    NB_V(2, 16, kSmem, true, 8),  // 2: j stream through the scalar cache, no LDS (within 1 % of 4)
+    NB_V(4, 16, kLds, true, 2),   // 3: 4 bodies per lane, 16 waves, j loop unrolled 2x
+    NB_V(4, 16, kLds, true, 4),   // 4: default -- 4 bodies per lane, 16 waves, unrolled 4x
+#ifdef NB_ALL_VARIANTS
+    NB_V(2, 8, kSmem, false, 8), NB_V(2, 8, kSmem, true, 8), NB_V(2, 4, kLds, false, 8),
+    NB_V(2, 4, kLds, true, 8), NB_V(4, 8, kLds, false, 4), NB_V(4, 8, kLds, true, 4),
+    NB_V(4, 4, kLds, true, 4), NB_V(1, 8, kLds, false, 8), NB_V(1, 16, kLds, false, 8),
+    NB_V(2, 16, kLds, false, 8), NB_V(2, 16, kLds, true, 8), NB_V(4, 8, kSmem, true, 4),
+    NB_V(4, 8, kLds, true, 2), NB_V(4, 16, kSmem, true, 2), NB_V(2, 16, kLds, true, 4),
+    NB_V(4, 16, kLds, true, 1), NB_V(8, 16, kLds, true, 1), NB_V(8, 8, kLds, true, 1),
+    NB_V(4, 16, kLds, true, 8), NB_V(4, 8, kLds, true, 8), NB_V(2, 16, kLds, true, 16),
+    NB_V(4, 16, kSmem, true, 4), NB_V(2, 16, kSmem, true, 16), NB_V(2, 16, kSmem, true, 4),
+#endif
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 // Default choice by the number of bodies this launch owns.  Measured on MI355X at N = 65536
 // (profiles/r01_variant_sweep*.txt): 4 bodies per lane, packed fp32, 16 waves per workgroup,
-// j loop unrolled 4x (variant 20) is the fastest single-kernel shape at 256 workgroups; with fewer i-tiles than
+// j loop unrolled 4x (variant 4) is the fastest single-kernel shape at 256 workgroups; with fewer i-tiles than
 // CUs the j range is additionally split over JS workgroups per i-tile so that >= ~256
 // workgroups (4 waves per SIMD on every CU) are in flight.
-constexpr int kAutoVariant = 20;  // ib4_w16 packed, j loop unrolled 4x
+constexpr int kAutoVariant = 4;   // ib4_w16 packed, j loop unrolled 4x
 constexpr uint32_t kTargetBlocks = 256;  // one 16-wave workgroup per CU
 constexpr uint32_t kMaxJSplit = 32;
 

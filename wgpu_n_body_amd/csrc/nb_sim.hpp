@@ -15,7 +15,7 @@ class SimBase {
 
     int setup_common(const nb_sim_params &p, const nb_add_params &ap, const nb_placement *pl);
     int bind_device() const;
-    int wait();
+    virtual int wait();  // device.poll(Wait); a TreeSim also reports its device status words
 
     virtual int init(const nb_particle *host, size_t count) = 0;          // Simulator::new
     virtual int encode() = 0;                                             // Simulator::encode

@@ -845,6 +845,253 @@ __global__ __launch_bounds__(256) void walk_kernel(
     acc_dst[i] = float4{fx, fy, fz, 0.f};
 }
 
+// ---- 8b. walk with the CELLS across the lanes ---------------------------------------------------
+// The kernel above gives every lane a body and feeds the wave one cell at a time, so a cell that
+// only a few of the 64 bodies need still costs a full wave instruction: at 2^20 bodies, theta 0.5,
+// a wave evaluates 2,417 cells for bodies that need 1,011 each (42 % of the lanes do useful work,
+// 17 % at depth 7 -- tools/walk_model.c).  Here the roles are transposed: a wave walks for a GROUP
+// of G consecutive bodies (G = 4, 8 or 16) whose drifted positions sit in SGPRs, and its 64 lanes
+// hold 64 CELLS of the traversal frontier, each with the G-bit set of bodies that have to test it.
+// One batch = pop up to 64 (cell, visit mask) entries from the wave's LDS stack, every lane loads its
+// own cell's 32-byte record (all bytes used), then for each of the G bodies one straight-line
+// evaluation of acceptance test + force over the 64 cells, with the body's coordinates as scalar
+// operands; lanes whose cell was opened by some body push its children (siblings stay adjacent
+// in the stack, so the next batch's record loads coalesce).  Every lane accumulates G partial
+// sums, added across the lanes once at the end of the walk in a fixed order.
+//   * each body still applies ITS OWN acceptance test to exactly the cells the reference's
+//     per-thread walk visits (tree.wgsl:57-70): visit and accept counts equal the oracle's;
+//   * lane slots are wasted only where a cell concerns a subset of the G bodies: 65 % useful at
+//     G = 8 (72 % at G = 4), and the scalar bookkeeping of the per-cell loop is gone;
+//   * a walk is a chain of ~25 batches instead of ~2,400 dependent cell visits, which is what
+//     bounds the small problems (benches/benchmark.rs sizes).
+struct CellEnt {
+    uint32_t id, mask;  // bit 31 - b of mask: body b of the group has to test the cell
+};
+
+// The per-body lane sets come out of the per-lane masks one bit at a time through the carry of an
+// add: v <<= 1, the lanes whose top bit was set are returned as a 64-bit lane mask (one VALU
+// instruction, where an and + compare would be two) ...
+__device__ __forceinline__ uint64_t shl1_carry_out(uint32_t &v) {
+    uint32_t o;
+    uint64_t c;
+    asm("v_add_co_u32_e64 %0, %1, %2, %2" : "=v"(o), "=s"(c) : "v"(v));
+    v = o;
+    return c;
+}
+// ... and go back in the same way: (v << 1) | (lane in `bit`), one add-with-carry
+__device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
+    uint32_t o;
+    uint64_t unused;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(o), "=s"(unused) : "v"(v), "s"(bit));
+    return o;
+}
+#ifndef NB_CELL_STACK
+#define NB_CELL_STACK 1024
+#endif
+#ifndef NB_WALK_WAVES
+#define NB_WALK_WAVES 1
+#endif
+constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (8 KiB); see the batch-size rule in the loop
+constexpr uint32_t kCellReserve = 160;
+
+#define NB_DPP(old, src, ctrl, row_mask) \
+    ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (row_mask), 0xf, false))
+
+// inclusive prefix sum over the 64 lanes (row_shr within the 16-lane rows, then the row totals)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
+    x += NB_DPP(0, x, 0x111, 0xf);  // row_shr:1
+    x += NB_DPP(0, x, 0x112, 0xf);  // row_shr:2
+    x += NB_DPP(0, x, 0x114, 0xf);  // row_shr:4
+    x += NB_DPP(0, x, 0x118, 0xf);  // row_shr:8
+    x += NB_DPP(0, x, 0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+    x += NB_DPP(0, x, 0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// sum over the 64 lanes, in a fixed order; the total lands in lane 63
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    uint32_t x = __float_as_uint(v);
+#define NB_STEP(ctrl, row_mask) \
+    x = __float_as_uint(__uint_as_float(x) + __uint_as_float(NB_DPP(0, x, ctrl, row_mask)))
+    NB_STEP(0x111, 0xf);
+    NB_STEP(0x112, 0xf);
+    NB_STEP(0x114, 0xf);
+    NB_STEP(0x118, 0xf);
+    NB_STEP(0x142, 0xa);
+    NB_STEP(0x143, 0xc);
+#undef NB_STEP
+    return __uint_as_float(x);
+}
+
+// roots.id[0 .. split) are walked together and reduced, then roots.id[split .. count): a LET host
+// may walk its own tree (PART 1) while the imports are on the wire and add them later (PART 2),
+// and gets bit for bit what the one-launch step (PART 0) computes.
+template <int G, bool COUNT, int PART>
+__global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
+    const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
+    const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots, uint32_t split,
+    float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
+    uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
+    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
+    __shared__ CellEnt s_stack[4][kCellStack];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t per_xcd = gridDim.x / 8u;  // as walk_kernel: an XCD walks one contiguous eighth
+    uint32_t blk = blockIdx.x;
+    if (blk < per_xcd * 8u) blk = (blk & 7u) * per_xcd + (blk >> 3);
+    const uint32_t i0 = lo + (blk * 4u + wave) * (uint32_t)G;  // the group: bodies i0 .. i0+G-1
+    if (i0 >= hi) return;                                      // wave-uniform; the kernel has no barrier
+    const uint32_t nvalid = min((uint32_t)G, hi - i0);
+    const uint32_t ib = i0 + lane;
+    const bool owner = lane < nvalid;  // lane b < G owns body b: loads it, integrates it at the end
+    const uint32_t ic = owner ? ib : i0;
+    const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
+    const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
+    const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
+    float bx[G], by[G], bz[G];  // the group's evaluation points, wave-uniform (SGPRs)
+#pragma unroll
+    for (int b = 0; b < G; ++b) {
+        bx[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xi), b));
+        by[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(yi), b));
+        bz[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(zi), b));
+    }
+    const float theta2 = theta * theta;
+    const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
+    CellEnt *stack = s_stack[wave];
+    float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
+    if (PART == 2 && owner) {
+        const float4 part = acc_dst[ib];
+        tx = part.x;
+        ty = part.y;
+        tz = part.z;
+    }
+    unsigned long long n_visits = 0, n_accepts = 0;
+    uint32_t n_cells = 0, n_leaves = 0, n_batches = 0, max_sp = 0;
+
+    for (uint32_t set = 0; set < 2u; ++set) {
+        const uint32_t r_lo = set == 0u ? 0u : split, r_hi = set == 0u ? min(split, roots.count) : roots.count;
+        if (r_lo >= r_hi) continue;
+        uint32_t sp = r_hi - r_lo;
+        if (lane < sp) stack[lane] = CellEnt{roots.id[r_lo + lane], group_mask};
+        __builtin_amdgcn_wave_barrier();
+        float ax[G], ay[G], az[G];
+#pragma unroll
+        for (int b = 0; b < G; ++b) ax[b] = ay[b] = az[b] = 0.f;
+
+        while (sp > 0u) {
+            // Batch size: up to 64 cells, fewer when their children (at most 8 each: 7 net per
+            // popped cell) would eat into the reserve.  Popping from the top keeps the walk
+            // depth-first, so once batches are down to one cell the stack grows by at most 7 per
+            // level below the cell it started from: 7 x 21 = 147 < kCellReserve slots, and a batch of
+            // several cells is only taken while it leaves the reserve untouched -- the stack cannot
+            // overflow on a consistent tree (the check below guards against a corrupt one).
+            const uint32_t free_slots = kCellStack - sp;
+            const uint32_t lim = free_slots > kCellReserve ? (free_slots - kCellReserve) / 7u : 0u;
+            const uint32_t c = max(1u, min(min(64u, sp), lim));
+            if (free_slots < 7u) {
+                if (lane == 0u) atomicAdd(&status[3], 1u);
+                break;
+            }
+            sp -= c;
+            const bool active = lane < c;
+            CellEnt ent{0u, 0u};
+            if (active) ent = stack[sp + lane];
+            NodeRec r{float4{0.f, 0.f, 0.f, 0.f}, 0u, 0u, ~0u, -1.0f};
+            if (active) r = rec[ent.id];
+            const uint32_t vm = ent.mask;  // bodies that test this cell, body b at bit 31 - b (0 on idle lanes)
+            // a leaf is never taken by its own body (self excluded by identity);
+            // cells carry self_pos = ~0, which is no body of the group
+            const uint32_t sb = r.self_pos - i0;
+            uint32_t vbits = vm, tbits = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
+            uint32_t om = 0u;  // bodies that open the cell (body b ends up at bit G - 1 - b)
+            const float4 q = r.cogm;
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const float dx = q.x - bx[b], dy = q.y - by[b], dz = q.z - bz[b];
+                const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
+                // negative size makes it always true.  Lane sets as 64-bit scalar masks.
+                const uint64_t far = __ballot(r.ssize2 < theta2 * r2);
+                const uint64_t take = far & shl1_carry_out(tbits);
+                const uint64_t open = shl1_carry_out(vbits) & ~far;
+                const float dist = __builtin_amdgcn_sqrtf(r2);
+                float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
+                w = __builtin_amdgcn_inverse_ballot_w64(take) ? w : 0.0f;  // predicated, not branched
+                ax[b] = __builtin_fmaf(w, dx, ax[b]);
+                ay[b] = __builtin_fmaf(w, dy, ay[b]);
+                az[b] = __builtin_fmaf(w, dz, az[b]);
+                om = shl1_carry_in(om, open);
+                if (COUNT) n_accepts += __builtin_amdgcn_inverse_ballot_w64(take) ? 1ull : 0ull;
+            }
+            om <<= 32 - G;  // back to the stack's format: body b at bit 31 - b
+            if (COUNT) {
+                n_visits += (unsigned long long)__popc(vm);
+                n_cells += c;
+                n_batches += 1u;
+                n_leaves += (uint32_t)__popcll(__ballot(active && r.count == 0u));
+            }
+            // push the children of the opened cells: lane l writes its cnt entries at
+            // sp + (children of the lanes below it), so siblings and cousins stay in lane order
+            const uint32_t cnt = om ? r.count : 0u;
+            const uint32_t incl = wave_scan_u32(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            CellEnt *dst = stack + sp + (incl - cnt);
+            // Every pushing lane stores all 8 slots, highest first, without looking at its count: a
+            // slot past a lane's count lands on a LOWER-numbered slot of a lane above it, which that
+            // lane stores later (or beyond the new top, inside the reserve) -- one predicate for
+            // the eight stores instead of eight.
+            if (cnt != 0u) {
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    dst[j] = CellEnt{r.first + (uint32_t)j, om};
+                    __builtin_amdgcn_wave_barrier();  // keep the stores in this order
+                }
+            }
+            sp += total;
+            if (COUNT) max_sp = max(max_sp, sp);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the G sums of this root set: add the 64 lanes' partial sums in a fixed order, hand body
+        // b's total to lane b
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const float sx = wave_sum_to_lane63(ax[b]), sy = wave_sum_to_lane63(ay[b]),
+                        sz = wave_sum_to_lane63(az[b]);
+            const float ux = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sx), 63));
+            const float uy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sy), 63));
+            const float uz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sz), 63));
+            if (lane == (uint32_t)b) {
+                tx += ux;
+                ty += uy;
+                tz += uz;
+            }
+        }
+        if (PART == 1) break;  // the own tree only
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], n_visits);
+        atomicAdd(&counters[1], n_accepts);
+        if (lane == 0u) {
+            atomicAdd(&counters[2], (unsigned long long)n_cells);
+            atomicMax(&counters[3], (unsigned long long)max_sp);
+            atomicAdd(&counters[4], (unsigned long long)n_leaves);
+            atomicMax(&counters[5], (unsigned long long)n_cells);  // the longest walk of any group
+            atomicAdd(&counters[6], (unsigned long long)n_batches);
+            atomicAdd(&counters[7], (unsigned long long)n_batches * (unsigned long long)(64 * G));
+        }
+    }
+    if (!owner) return;
+    if (PART == 1) {
+        acc_dst[ib] = float4{tx, ty, tz, 0.f};
+        return;
+    }
+    const float gdt = g * dt;
+    const float fx = tx * gdt, fy = ty * gdt, fz = tz * gdt;
+    posm_dst[ib] = float4{xi, yi, zi, p.w};
+    vel_dst[ib] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
+    acc_dst[ib] = float4{fx, fy, fz, 0.f};
+}
+
 // ---- 9. locally essential trees (multi-GPU Barnes-Hut) ------------------------
 // Every rank owns a Morton range of the bodies and builds the octree of ITS bodies inside the
 // GLOBAL root cube.  What a peer needs of that tree to walk it for its own bodies is the
@@ -1142,6 +1389,7 @@ class TreeSim final : public SimBase {
         drop_graph();
         for (void *p : allocs) (void)hipFree(p);
         for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+        if (h_status) (void)hipHostFree(h_status);
     }
 
     int init(const nb_particle *host, size_t count) override {
@@ -1196,6 +1444,7 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&counters, sizeof(unsigned long long) * 8)) return rc;
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 64, stream));
         NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream));
+        NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 4, hipHostMallocDefault));
         return write_particles(host, count);
     }
 
@@ -1378,7 +1627,8 @@ class TreeSim final : public SimBase {
                 if (let_segs.off[r + 1] > let_segs.off[r]) roots.id[roots.count++] = node_cap + let_segs.off[r];
         }
         if (n) {
-            if (int rc = enqueue_walk(roots, let_own_walked ? 2 : 0)) return rc;
+            // set 0 = the own tree (already walked by NB_PHASE_LET_WALK_OWN if let_own_walked), set 1 = the imports
+            if (int rc = enqueue_walk(roots, let_own_walked ? 2 : 0, let_own_walked ? 0u : 1u)) return rc;
         }
         let_own_walked = false;
         step_num += 1;
@@ -1617,7 +1867,7 @@ class TreeSim final : public SimBase {
     }
 
     // part: 0 whole step, 1 own-tree sums only, 2 continue from those sums and integrate
-    int enqueue_walk(const WalkRoots &roots, int part = 0) {
+    int enqueue_walk(const WalkRoots &roots, int part = 0, uint32_t split = 1) {
         const int s = cur, d = cur ^ 1;
         uint32_t *status = scalars + 4;
         const dim3 b256(256);
@@ -1626,7 +1876,7 @@ class TreeSim final : public SimBase {
                                vel[d], acc[d]);
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
-        if (hi > lo) {
+        if (hi > lo && walk_mode == 0) {
             // bodies per wave: 64 when that still gives >= 4096 waves (4 per SIMD), else halve down to 8
             uint32_t shift = 6;
             if (walk_bpw) {
@@ -1645,6 +1895,29 @@ class TreeSim final : public SimBase {
             } else {
                 if (part == 0) NB_WALK(false, 0); else if (part == 1) NB_WALK(false, 1); else NB_WALK(false, 2);
             }
+#undef NB_WALK
+        } else if (hi > lo) {
+            // cells across the lanes (section 8b): a wave walks for a group of G bodies
+            const uint32_t gsize = walk_group ? walk_group : 8u;
+            const uint32_t per_block = 4u * gsize;
+            const dim3 gwalk((hi - lo + per_block - 1) / per_block);
+#define NB_WALK(G, COUNT, PART)                                                                               \
+    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d],  \
+                       rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt,     \
+                       theta, status, counters)
+#define NB_WALK_P(G, COUNT)                                                                   \
+    do {                                                                                      \
+        if (part == 0) NB_WALK(G, COUNT, 0); else if (part == 1) NB_WALK(G, COUNT, 1); else NB_WALK(G, COUNT, 2); \
+    } while (0)
+#define NB_WALK_G(COUNT)                                          \
+    do {                                                          \
+        if (gsize == 4u) NB_WALK_P(4, COUNT);                     \
+        else if (gsize == 16u) NB_WALK_P(16, COUNT);              \
+        else NB_WALK_P(8, COUNT);                                 \
+    } while (0)
+            if (count_visits) NB_WALK_G(true); else NB_WALK_G(false);
+#undef NB_WALK_G
+#undef NB_WALK_P
 #undef NB_WALK
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
@@ -1666,9 +1939,26 @@ class TreeSim final : public SimBase {
         return check_status();
     }
 
+    // device.poll(Wait) (offline_headless.rs:43) + the device status words: a step that overflowed
+    // the 4N node buffer, cut a LET export short, met inseparable bodies or tripped the walk's
+    // stack guard must not look like a good step to a caller that never reads particles back
+    // (nb_runner_step, the headless CLI, timing loops).  The words ride the same stream: one
+    // 16-byte copy into pinned memory ahead of the one synchronisation.
+    int wait() override {
+        if (int rc = bind_device()) return rc;
+        if (!h_status || !scalars) return SimBase::wait();
+        NB_HIP_TRY(hipMemcpyAsync(h_status, scalars + 4, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        NB_HIP_TRY(hipStreamSynchronize(stream));
+        return report_status(h_status);
+    }
+
     int check_status() {
         uint32_t st[4] = {0, 0, 0, 0};
         NB_HIP_TRY(hipMemcpy(st, scalars + 4, sizeof st, hipMemcpyDeviceToHost));
+        return report_status(st);
+    }
+
+    int report_status(const uint32_t *st) {
         if (st[0]) {
             set_error("LET export needs more than tree_let_cap = %u records for a peer (%u cells cut short)",
                       let_cap, st[0]);
@@ -1682,6 +1972,12 @@ class TreeSim final : public SimBase {
         if (st[1]) {
             set_error("octree needs more than %u nodes (4N, the reference's capacity, tree.rs:188-190)",
                       node_cap);
+            return NB_ERR_UNSUPPORTED;
+        }
+        if (st[2]) {
+            set_error("%u bodies share their 63-bit Morton key with a neighbour (closer than root_width / 2^21): "
+                      "the octree cannot separate them (the reference's build_tree, tree.rs:473-544, never "
+                      "terminates on such input)", st[2]);
             return NB_ERR_UNSUPPORTED;
         }
         return NB_OK;
@@ -1747,7 +2043,7 @@ class TreeSim final : public SimBase {
         }
         if (ms_total) *ms_total = total;
         if (ms_kernel) *ms_kernel = walk_sum / (float)count;  // the dominant kernel: the walk
-        return NB_OK;
+        return check_status();  // a degraded step must not be reported as a timing
     }
 
     // Sharded TreeSim = replicated tree, partitioned walk: after encode the
@@ -1804,6 +2100,20 @@ class TreeSim final : public SimBase {
         }
         if (std::strcmp(key, "tree_walk_bpw") == 0) {  // bodies per wave: 0 = automatic, else 8/16/32/64
             walk_bpw = value < 0 ? 0 : (uint32_t)value;
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_walk_mode") == 0) {  // 0: bodies across the lanes, 1: cells across the lanes
+            walk_mode = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_walk_group") == 0) {  // bodies per wave of mode 1: 0 = automatic, else 4/8/16
+            if (value != 0 && value != 4 && value != 8 && value != 16) {
+                set_error("tree_walk_group must be 0, 4, 8 or 16");
+                return NB_ERR_INVALID;
+            }
+            walk_group = (uint32_t)value;
             drop_graph();
             return NB_OK;
         }
@@ -1893,6 +2203,7 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
+    uint32_t walk_mode = 1, walk_group = 0;
     bool build_done = false;  // phase 0 of the next step already enqueued
     // locally essential trees (section 9); let_world == 0: not in use
     int let_world = 0, let_rank = 0, let_next = 0;
@@ -1906,6 +2217,7 @@ class TreeSim final : public SimBase {
     float4 *let_mig_send = nullptr, *let_mig_recv = nullptr;
     LetOwners let_owners{};
     hipGraphExec_t graph_exec = nullptr;
+    uint32_t *h_status = nullptr;  // pinned mirror of the device status words (wait())
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
