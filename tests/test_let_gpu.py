@@ -247,8 +247,8 @@ def test_let_export_capacity_is_checked(gpu):
     nb = gpu
     sp, p = tagged(nb, 4000, 25)
     grp = LetGroup(nb, sp, p, 2, 0.3, cap=64)     # far too small for a neighbour's LET
-    grp.step()
-    with pytest.raises(nb.NBodyError) as ex:
+    with pytest.raises(nb.NBodyError) as ex:      # reported by the first wait after the export
+        grp.step()
         for s in grp.sims:
             s.dest_particle_slice()
     assert "tree_let_cap" in str(ex.value)
@@ -352,17 +352,22 @@ def test_let_migration_keeps_the_waves_coherent(gpu):
     nb = gpu
     n, world, steps = 60000, 4, 6
     sp, p = moving(nb, n, 32, 0.3)
+    # (walk mode 0: one wave walks for 64 bodies, where a handful of strays costs the whole wave)
     longest = {}
-    for every in (0, 1):
-        grp = LetGroup(nb, sp, p, world, 0.5, migrate_every=every)
-        for s in grp.sims:
-            s.set_tuning("tree_count_visits", 1)
-            s.set_tuning("tree_walk_bpw", 64)     # full waves, as on a large problem
-        for _ in range(steps):
-            grp.step()
-        longest[every] = max(int(s.debug_buffer("counters", np.uint64)[5]) for s in grp.sims)
-        grp.destroy()
-    assert longest[1] < 0.5 * longest[0], longest
+    for mode in (0, 1):
+        for every in (0, 1):
+            grp = LetGroup(nb, sp, p, world, 0.5, migrate_every=every)
+            for s in grp.sims:
+                s.set_tuning("tree_count_visits", 1)
+                s.set_tuning("tree_walk_mode", mode)
+                s.set_tuning("tree_walk_bpw", 64)     # full waves, as on a large problem
+            for _ in range(steps):
+                grp.step()
+            longest[mode, every] = max(int(s.debug_buffer("counters", np.uint64)[5]) for s in grp.sims)
+            grp.destroy()
+    assert longest[0, 1] < 0.5 * longest[0, 0], longest
+    # groups of 8 bodies (mode 1, the default) suffer less from strays, but still gain
+    assert longest[1, 1] < 0.8 * longest[1, 0], longest
 
 
 @pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap"), (3, "let-rebalance")])

@@ -2,7 +2,7 @@
 # SQ counters of the Barnes-Hut walk kernel (run through gpurun).  Two --pmc passes of <= 8 SQ
 # counters each, kernel-trace only (no other trace domains).  Prints per-launch averages.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_tree_pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -16,7 +16,7 @@ for p in ("p1", "p2"):
     f = glob.glob("$OUT/%s/**/*_counter_collection.csv" % p, recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "walk_kernel" in r["Kernel_Name"]:
+        if "walk_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print("%-24s %16.0f  (avg of %d launches)" % (k, sum(v) / len(v), len(v)))

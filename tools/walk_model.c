@@ -131,10 +131,10 @@ static void walk_group(uint32_t lo, int G, float theta2, Stats *st) {
 // against each of the G bodies, the children of opened cells are pushed (siblings contiguous).
 typedef struct { uint32_t id; uint32_t mask; } CEnt;
 typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any; } CStats;
-static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st) {
+static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, CStats *st) {
     static _Thread_local CEnt stack[1 << 16];
     int sp = 0, hw = 0;
-    stack[sp++] = (CEnt){0, (G == 32 ? 0xffffffffu : ((1u << G) - 1))};
+    stack[sp++] = (CEnt){0, (nb == 32 ? 0xffffffffu : ((1u << nb) - 1))};
     while (sp > 0) {
         const int c = sp < batch ? sp : batch;
         CEnt cur[64];
@@ -146,7 +146,7 @@ static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st
             const Rec *r = &rec[cur[l].id];
             uint32_t open = 0;
             any |= cur[l].mask;
-            for (int b = 0; b < G; ++b) {
+            for (int b = 0; b < nb; ++b) {
                 if (!((cur[l].mask >> b) & 1)) continue;
                 const f4 p = kp[lo + b].p;
                 const float dx = r->cogm.x - p.x, dy = r->cogm.y - p.y, dz = r->cogm.z - p.z;
@@ -163,6 +163,8 @@ static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st
     st->hw += hw;
     if (hw > st->maxhw) st->maxhw = hw;
 }
+
+static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st) { walk_group_c2(lo, G, G, theta2, batch, st); }
 
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atol(argv[1]) : 1u << 20;
@@ -245,6 +247,34 @@ int main(int argc, char **argv) {
         printf(" G %2d: batches/group %.1f  cells/group %.1f  fill %.3f  pair-instr per 64 bodies %.0f  util %.3f  (skipping bodies absent from a batch: %.0f, util %.3f)  stack high water mean %.0f max %.0f\n",
                G, tot.batches / ngroups, tot.cells / ngroups, tot.cells / (tot.batches * 64), tot.pairs / 64 / ngroups * (64 / G),
                tot.visits / tot.pairs, tot.pairs_any / 64 / ngroups * (64 / G), tot.visits / tot.pairs_any, tot.hw / ngroups, tot.maxhw);
+    }
+
+    printf("\nscheme C with cell-aligned groups (a group never straddles a cell of > 8 bodies), G = 8 slots\n");
+    {
+        // greedy: walk sorted bodies; group = longest run of <= 8 bodies sharing the key prefix of the
+        // smallest cell that holds the first body and has <= 8 bodies
+        CStats tot; memset(&tot, 0, sizeof tot);
+        double ngroups = 0, nbodies = 0;
+        uint32_t i = 0;
+        // sample a contiguous range
+        const uint32_t start = n / 3, stop = start + 65536;
+        i = start;
+        while (i < stop) {
+            int best = 1;
+            for (int d = 1; d <= 20; ++d) {   // shallowest cell containing body i with <= 8 bodies
+                const int shift = 3 * (21 - d);
+                const uint64_t pre = kp[i].key >> shift;
+                uint32_t a = i, b2 = i;
+                while (a > 0 && (kp[a - 1].key >> shift) == pre) --a;
+                while (b2 + 1 < n && (kp[b2 + 1].key >> shift) == pre) ++b2;
+                if (b2 - a + 1 <= 8) { best = (int)(b2 - i + 1); break; }
+            }
+            walk_group_c2(i, best, 8, theta * theta, 64, &tot);
+            ngroups += 1; nbodies += best;
+            i += best;
+        }
+        printf(" groups %.0f mean size %.2f; pair-instr per 64 bodies %.0f (batches per 64 bodies %.1f)\n", ngroups, nbodies / ngroups,
+               tot.pairs / 64 / nbodies * 64, tot.batches / nbodies * 64);
     }
     return 0;
 }

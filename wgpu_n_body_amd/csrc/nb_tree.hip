@@ -886,12 +886,16 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
     return o;
 }
 #ifndef NB_CELL_STACK
-#define NB_CELL_STACK 1024
+#define NB_CELL_STACK 896
 #endif
 #ifndef NB_WALK_WAVES
 #define NB_WALK_WAVES 1
 #endif
-constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (8 KiB); see the batch-size rule in the loop
+#ifndef NB_WALK_BLOCK_WAVES
+#define NB_WALK_BLOCK_WAVES 1
+#endif
+constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
+constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (7 KiB); see the batch-size rule in the loop
 constexpr uint32_t kCellReserve = 160;
 
 #define NB_DPP(old, src, ctrl, row_mask) \
@@ -923,23 +927,66 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return __uint_as_float(x);
 }
 
+// One batch of the cells walk: the lane's cell (q = centre of gravity + mass, ssize2) against the G
+// bodies of the group.  vm: the bodies that have to test the cell (body b at bit 31 - b); returns
+// the bodies that open it (same format).  SELF: some lane of the batch holds the leaf of one of
+// the group's own bodies (tm = vm without that body: a leaf is never taken by its own body, SURVEY
+// A14) -- true for one batch of a walk, so the common path spends nothing on it.
+template <int G, bool SELF, bool COUNT>
+__device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssize2, uint32_t vm, uint32_t tm,
+                                                const float (&bx)[G], const float (&by)[G],
+                                                const float (&bz)[G], const float theta2, const float e,
+                                                float (&ax)[G], float (&ay)[G], float (&az)[G],
+                                                unsigned long long &n_accepts) {
+    uint32_t om = 0u;  // body b ends up at bit G - 1 - b
+#pragma unroll
+    for (int b = 0; b < G; ++b) {
+        const float dx = q.x - bx[b], dy = q.y - by[b], dz = q.z - bz[b];
+        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
+        // negative size makes it always true.  Lane sets as 64-bit scalar masks.
+        const uint64_t far = __ballot(ssize2 < theta2 * r2);
+        const uint64_t visit = shl1_carry_out(vm);
+        const uint64_t take = far & (SELF ? shl1_carry_out(tm) : visit);
+        const uint64_t open = visit & ~far;
+        const float dist = __builtin_amdgcn_sqrtf(r2);
+        float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
+        w = __builtin_amdgcn_inverse_ballot_w64(take) ? w : 0.0f;  // predicated, not branched
+        ax[b] = __builtin_fmaf(w, dx, ax[b]);
+        ay[b] = __builtin_fmaf(w, dy, ay[b]);
+        az[b] = __builtin_fmaf(w, dz, az[b]);
+        om = shl1_carry_in(om, open);
+        if (COUNT) n_accepts += __builtin_amdgcn_inverse_ballot_w64(take) ? 1ull : 0ull;
+#ifdef NB_DIAG_EXTRA_VALU   // sensitivity probe: two more transcendentals and three fma per pair
+        {
+            const float t = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r2 + 1.0f));
+            float u = __builtin_fmaf(t, dx, dy);
+            u = __builtin_fmaf(t, u, dz);
+            u = __builtin_fmaf(t, u, dx);
+            asm volatile("" ::"v"(u));
+        }
+#endif
+    }
+    return om << (32 - G);  // the stack's format: body b at bit 31 - b
+}
+
 // roots.id[0 .. split) are walked together and reduced, then roots.id[split .. count): a LET host
 // may walk its own tree (PART 1) while the imports are on the wire and add them later (PART 2),
 // and gets bit for bit what the one-launch step (PART 0) computes.
 template <int G, bool COUNT, int PART>
-__global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
+__global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_cells_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
-    __shared__ CellEnt s_stack[4][kCellStack];
+    __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t per_xcd = gridDim.x / 8u;  // as walk_kernel: an XCD walks one contiguous eighth
     uint32_t blk = blockIdx.x;
     if (blk < per_xcd * 8u) blk = (blk & 7u) * per_xcd + (blk >> 3);
-    const uint32_t i0 = lo + (blk * 4u + wave) * (uint32_t)G;  // the group: bodies i0 .. i0+G-1
+    const uint32_t i0 = lo + (blk * kCellBlockWaves + wave) * (uint32_t)G;  // the group: bodies i0 .. i0+G-1
     if (i0 >= hi) return;                                      // wave-uniform; the kernel has no barrier
     const uint32_t nvalid = min((uint32_t)G, hi - i0);
     const uint32_t ib = i0 + lane;
@@ -955,7 +1002,22 @@ __global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
         by[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(yi), b));
         bz[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(zi), b));
     }
+    // bounding box of the group's evaluation points (for the all-open shortcut below)
+    float blx = bx[0], bly = by[0], blz = bz[0], bhx = bx[0], bhy = by[0], bhz = bz[0];
+#pragma unroll
+    for (int b = 1; b < G; ++b) {
+        if ((uint32_t)b < nvalid) {
+            blx = fminf(blx, bx[b]); bhx = fmaxf(bhx, bx[b]);
+            bly = fminf(bly, by[b]); bhy = fmaxf(bhy, by[b]);
+            blz = fminf(blz, bz[b]); bhz = fmaxf(bhz, bz[b]);
+        }
+    }
+    // (wave-uniform values computed by the vector unit: move them to SGPRs)
+#define NB_UNIFORM(x) x = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)))
+    NB_UNIFORM(blx); NB_UNIFORM(bly); NB_UNIFORM(blz); NB_UNIFORM(bhx); NB_UNIFORM(bhy); NB_UNIFORM(bhz);
+#undef NB_UNIFORM
     const float theta2 = theta * theta;
+    const uint32_t root0 = roots.id[0];  // a record every idle lane may read
     const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
     CellEnt *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
@@ -967,6 +1029,9 @@ __global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
     }
     unsigned long long n_visits = 0, n_accepts = 0;
     uint32_t n_cells = 0, n_leaves = 0, n_batches = 0, max_sp = 0;
+#ifdef NB_DIAG_PHASES
+    unsigned long long ph[4] = {0, 0, 0, 0};
+#endif
 
     for (uint32_t set = 0; set < 2u; ++set) {
         const uint32_t r_lo = set == 0u ? 0u : split, r_hi = set == 0u ? min(split, roots.count) : roots.count;
@@ -993,43 +1058,65 @@ __global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
                 break;
             }
             sp -= c;
+#ifdef NB_DIAG_PHASES
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+            // idle lanes (a batch of fewer than 64 cells) read a live stack slot and the root's
+            // record like everybody else and carry an empty visit mask: no divergent loads
             const bool active = lane < c;
-            CellEnt ent{0u, 0u};
-            if (active) ent = stack[sp + lane];
-            NodeRec r{float4{0.f, 0.f, 0.f, 0.f}, 0u, 0u, ~0u, -1.0f};
-            if (active) r = rec[ent.id];
-            const uint32_t vm = ent.mask;  // bodies that test this cell, body b at bit 31 - b (0 on idle lanes)
-            // a leaf is never taken by its own body (self excluded by identity);
-            // cells carry self_pos = ~0, which is no body of the group
-            const uint32_t sb = r.self_pos - i0;
-            uint32_t vbits = vm, tbits = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
-            uint32_t om = 0u;  // bodies that open the cell (body b ends up at bit G - 1 - b)
-            const float4 q = r.cogm;
-#pragma unroll
-            for (int b = 0; b < G; ++b) {
-                const float dx = q.x - bx[b], dy = q.y - by[b], dz = q.z - bz[b];
-                const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
-                // negative size makes it always true.  Lane sets as 64-bit scalar masks.
-                const uint64_t far = __ballot(r.ssize2 < theta2 * r2);
-                const uint64_t take = far & shl1_carry_out(tbits);
-                const uint64_t open = shl1_carry_out(vbits) & ~far;
-                const float dist = __builtin_amdgcn_sqrtf(r2);
-                float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-                w = __builtin_amdgcn_inverse_ballot_w64(take) ? w : 0.0f;  // predicated, not branched
-                ax[b] = __builtin_fmaf(w, dx, ax[b]);
-                ay[b] = __builtin_fmaf(w, dy, ay[b]);
-                az[b] = __builtin_fmaf(w, dz, az[b]);
-                om = shl1_carry_in(om, open);
-                if (COUNT) n_accepts += __builtin_amdgcn_inverse_ballot_w64(take) ? 1ull : 0ull;
+            const CellEnt top = stack[sp + (active ? lane : 0u)];
+            const uint32_t cell = active ? top.id : root0;
+            const uint32_t vm = active ? top.mask : 0u;  // bodies that test this cell, body b at bit 31 - b
+#ifdef NB_DIAG_PHASES
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(cell), "v"(vm));
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+            const NodeRec r = rec[cell];
+#ifdef NB_DIAG_PHASES
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(r.cogm.x), "v"(r.cogm.w), "v"(r.first), "v"(r.count), "v"(r.self_pos), "v"(r.ssize2));
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef NB_DIAG_EXTRA_LOAD   // sensitivity probe: one more divergent 32-byte record load per lane and batch
+            {
+                const NodeRec r2 = rec[cell ^ 1u];
+                asm volatile("" ::"v"(r2.cogm.x), "v"(r2.cogm.w), "v"(r2.first), "v"(r2.ssize2));
             }
-            om <<= 32 - G;  // back to the stack's format: body b at bit 31 - b
+#endif
+            // a leaf is never taken by its own body; cells carry self_pos = ~0, no body of the group
+            const uint32_t sb = r.self_pos - i0;
+            uint32_t om;
+            // The top of the tree: a batch of a few big cells (the root, its children; also the
+            // roots of imported trees) that EVERY body of the group opens.  One test per lane against
+            // the group's bounding box decides it without touching the bodies: with the largest
+            // per-axis distance to the box, r2max >= the r^2 any body computes (fp32 subtract,
+            // multiply and fma are monotonic, same operation order), so "not (size^2 < theta^2
+            // r2max)" implies every body's own test says open -- the same decisions, 1/8 of the work.
+            bool all_open = false;
+            if (c <= 8u) {
+                const float dxm = fmaxf(fabsf(r.cogm.x - blx), fabsf(r.cogm.x - bhx));
+                const float dym = fmaxf(fabsf(r.cogm.y - bly), fabsf(r.cogm.y - bhy));
+                const float dzm = fmaxf(fabsf(r.cogm.z - blz), fabsf(r.cogm.z - bhz));
+                const float r2max = __builtin_fmaf(dzm, dzm, __builtin_fmaf(dym, dym, dxm * dxm));
+                all_open = __ballot(active && (r.ssize2 < theta2 * r2max)) == 0ull;
+            }
+            if (all_open) {
+                om = vm;
+            } else if (__ballot(sb < (uint32_t)G) == 0ull) {
+                om = cells_batch<G, false, COUNT>(r.cogm, r.ssize2, vm, vm, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
+            } else {
+                const uint32_t tm = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
+                om = cells_batch<G, true, COUNT>(r.cogm, r.ssize2, vm, tm, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
+            }
             if (COUNT) {
                 n_visits += (unsigned long long)__popc(vm);
                 n_cells += c;
                 n_batches += 1u;
                 n_leaves += (uint32_t)__popcll(__ballot(active && r.count == 0u));
             }
+#ifdef NB_DIAG_PHASES
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(om), "v"(ax[0]), "v"(ay[G - 1]));
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
             // push the children of the opened cells: lane l writes its cnt entries at
             // sp + (children of the lanes below it), so siblings and cousins stay in lane order
             const uint32_t cnt = om ? r.count : 0u;
@@ -1050,21 +1137,41 @@ __global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
             sp += total;
             if (COUNT) max_sp = max(max_sp, sp);
             __builtin_amdgcn_wave_barrier();
+#ifdef NB_DIAG_PHASES
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"s"(sp));
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            ph[0] += t1 - t0;
+            ph[1] += t2 - t1;
+            ph[2] += t3 - t2;
+            ph[3] += t4 - t3;
+#endif
         }
-        // the G sums of this root set: add the 64 lanes' partial sums in a fixed order, hand body
-        // b's total to lane b
+        // The G sums of this root set, in a fixed order, through the (now empty) stack's LDS: every
+        // lane stores its G partial sums of one component; lane l then adds the partial sums of the
+        // lanes [p G, p G + G) of body b, with b = l / L, p = l % L, L = 64 / G lanes per body; the L
+        // results of a body meet by butterfly; lane b fetches body b's total.
+        {
+            constexpr uint32_t L = 64u / (uint32_t)G;
+            float *red = reinterpret_cast<float *>(stack);  // [G][64] floats <= 4 KiB of the 8 KiB stack
+            const uint32_t rb = lane / L, rp = lane % L;
+            float sum3[3];
 #pragma unroll
-        for (int b = 0; b < G; ++b) {
-            const float sx = wave_sum_to_lane63(ax[b]), sy = wave_sum_to_lane63(ay[b]),
-                        sz = wave_sum_to_lane63(az[b]);
-            const float ux = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sx), 63));
-            const float uy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sy), 63));
-            const float uz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sz), 63));
-            if (lane == (uint32_t)b) {
-                tx += ux;
-                ty += uy;
-                tz += uz;
+            for (int comp = 0; comp < 3; ++comp) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int b = 0; b < G; ++b) red[b * 64 + (int)lane] = comp == 0 ? ax[b] : comp == 1 ? ay[b] : az[b];
+                __builtin_amdgcn_wave_barrier();
+                float sacc = 0.f;
+#pragma unroll
+                for (int j = 0; j < G; ++j) sacc += red[rb * 64u + rp * (uint32_t)G + (uint32_t)j];
+#pragma unroll
+                for (uint32_t o = L / 2u; o > 0u; o >>= 1) sacc += __shfl_xor(sacc, (int)o);
+                sum3[comp] = __shfl(sacc, (int)((lane % (uint32_t)G) * L));  // lane b < G: body b's total
             }
+            __builtin_amdgcn_wave_barrier();
+            tx += sum3[0];
+            ty += sum3[1];
+            tz += sum3[2];
         }
         if (PART == 1) break;  // the own tree only
     }
@@ -1080,6 +1187,10 @@ __global__ __launch_bounds__(256, NB_WALK_WAVES) void walk_cells_kernel(
             atomicAdd(&counters[7], (unsigned long long)n_batches * (unsigned long long)(64 * G));
         }
     }
+#ifdef NB_DIAG_PHASES
+    if (lane == 0u)  // per-wave phase cycles, no atomics: counters + 16 + 4 * group index
+        for (int k = 0; k < 4; ++k) counters[16 + 4 * (size_t)((i0 - lo) / (uint32_t)G) + k] = ph[k];
+#endif
     if (!owner) return;
     if (PART == 1) {
         acc_dst[ib] = float4{tx, ty, tz, 0.f};
@@ -1441,9 +1552,13 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
         if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&scalars, sizeof(uint32_t) * 64)) return rc;
-        if (int rc = alloc(&counters, sizeof(unsigned long long) * 8)) return rc;
+        #ifdef NB_DIAG_PHASES
+        if (int rc = alloc(&counters, sizeof(unsigned long long) * (16 + nn + 8))) return rc;
+#else
+        if (int rc = alloc(&counters, sizeof(unsigned long long) * 16)) return rc;
+#endif
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 64, stream));
-        NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, stream));
+        NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 16, stream));
         NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 4, hipHostMallocDefault));
         return write_particles(host, count);
     }
@@ -1899,10 +2014,10 @@ class TreeSim final : public SimBase {
         } else if (hi > lo) {
             // cells across the lanes (section 8b): a wave walks for a group of G bodies
             const uint32_t gsize = walk_group ? walk_group : 8u;
-            const uint32_t per_block = 4u * gsize;
-            const dim3 gwalk((hi - lo + per_block - 1) / per_block);
+            const uint32_t per_block = kCellBlockWaves * gsize;
+            const dim3 gwalk((hi - lo + per_block - 1) / per_block), bwalk(64 * kCellBlockWaves);
 #define NB_WALK(G, COUNT, PART)                                                                               \
-    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d],  \
+    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, bwalk, 0, stream, posm[d], vel[d], acc[d],  \
                        rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt,     \
                        theta, status, counters)
 #define NB_WALK_P(G, COUNT)                                                                   \
@@ -2159,7 +2274,10 @@ class TreeSim final : public SimBase {
         size_t len = 0;
         const std::string nm(name);
         if (nm == "order") { src = order; len = sizeof(uint32_t) * n; }
-        else if (nm == "counters") { src = counters; len = sizeof(unsigned long long) * 8; }
+        else if (nm == "counters") { src = counters; len = sizeof(unsigned long long) * 16; }
+#ifdef NB_DIAG_PHASES
+        else if (nm == "phases") { src = counters + 16; len = sizeof(unsigned long long) * 4 * ((n + 3) / 4); }
+#endif
         else if (nm == "status") { src = scalars + 4; len = sizeof(uint32_t) * 4; }
         else if (nm == "depth_base") { src = scalars + 16; len = sizeof(uint32_t) * (kMaxDepth + 2); }
         else {
