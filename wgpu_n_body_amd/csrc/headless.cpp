@@ -2,7 +2,10 @@
 // criterion groups in benches/benchmark.rs:12-49) over the drop-in API of simulator.hpp.
 //
 //   headless [--sim naive|tree] [--n N] [--steps S] [--theta T] [--init uniform|disc|spherical]
-//            [--seed K] [--device D]
+//            [--seed K] [--device D] [--g G] [--dt DT] [--dump FILE]
+//
+// --dump FILE writes the final state as a snapshot (the layout of
+// wgpu_n_body_amd/snapshot.py: "NBSNAP01", u64 step, SimParams, Particle[n]).
 //
 // Defaults reproduce headless.rs: TreeSim, 4,000,000 bodies, theta 0.75, uniform_init,
 // 10 steps, printing "Step Duration: {} us" per step.  (TreeSim needs the Barnes-Hut build;
@@ -12,12 +15,23 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "simulator.hpp"
 
+static bool write_snapshot(const std::string &path, const nbody::SimParams &sp,
+                           const std::vector<nbody::Particle> &parts, uint64_t step) {
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = std::fwrite("NBSNAP01", 1, 8, f) == 8 && std::fwrite(&step, sizeof step, 1, f) == 1 &&
+              std::fwrite(&sp, sizeof sp, 1, f) == 1 &&
+              std::fwrite(parts.data(), sizeof(nbody::Particle), parts.size(), f) == parts.size();
+    return std::fclose(f) == 0 && ok;
+}
+
 template <class Sim>
 static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbody::InitFn &init,
-               int steps, int device) {
+               int steps, int device, const std::string &dump) {
     std::puts("Initializing Simulation");
     nbody::OfflineHeadless<Sim> runner(sp, ap, init, device);
     std::puts("Running Simulation");
@@ -29,11 +43,18 @@ static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbo
         std::printf("Step Duration: %lld \xC2\xB5s\n", (long long)us);
     }
     std::puts("Finished Running");
+    if (!dump.empty()) {
+        const std::vector<nbody::Particle> parts = runner.read_particles();
+        if (!write_snapshot(dump, sp, parts, runner.sim().step_num())) {
+            std::fprintf(stderr, "cannot write %s\n", dump.c_str());
+            return 1;
+        }
+    }
     return 0;
 }
 
 int main(int argc, char **argv) {
-    std::string sim = "tree", init = "uniform";
+    std::string sim = "tree", init = "uniform", dump;
     nbody::SimParams sp{4000000u, 0.000001f, 0.0001f, 0.016f};  // headless.rs:15-20
     float theta = 0.75f;
     int steps = 10, device = -1;
@@ -49,6 +70,7 @@ int main(int argc, char **argv) {
         else if (k == "--device") device = std::atoi(v.c_str());
         else if (k == "--g") sp.g = (float)std::atof(v.c_str());
         else if (k == "--dt") sp.dt = (float)std::atof(v.c_str());
+        else if (k == "--dump") dump = v;
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     const nbody::InitFn fn = init == "disc" ? nbody::inits::disc_init(seed)
@@ -56,8 +78,8 @@ int main(int argc, char **argv) {
                                                  : nbody::inits::uniform_init(seed);
     try {
         if (sim == "naive")
-            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device);
-        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device);
+            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device, dump);
+        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device, dump);
     } catch (const nbody::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code(), e.what());
         return 1;

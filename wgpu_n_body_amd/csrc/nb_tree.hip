@@ -285,6 +285,184 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
 }
 
+// ---- 3b. one-sweep radix sort: ONE launch per 8-bit digit ------------------------------------------
+// The three-kernel pass above (tile histograms, per-bin scan over the tiles, scatter) is launch-bound
+// on the small problems and reads the keys twice.  Here the digit histograms of ALL eight passes are
+// taken once, while the keys are generated (a digit's global histogram does not depend on the order
+// of the keys), and a pass is a single kernel: a workgroup takes the next tile by ticket, counts its
+// digits, publishes the counts, and finds where its digits start by looking BACK over the tiles before
+// it (decoupled look-back: per tile and digit one word {flag, count} -- "aggregate" = this tile's
+// count, "inclusive" = count of this and all earlier tiles -- written and polled with agent-scope
+// atomics, since the tiles before it may run on another XCD).  Tickets are handed out in launch
+// order, so every tile a workgroup waits for is already running: no deadlock; the spin is bounded
+// all the same and reports through status[3] rather than hanging the GPU.
+constexpr uint32_t kOsFlagAggregate = 1u << 30, kOsFlagInclusive = 2u << 30, kOsValueMask = (1u << 30) - 1u;
+constexpr uint32_t kOsSpinLimit = 1u << 22;
+
+// keys as morton_kernel, plus the eight global digit histograms (bin-major rows of 256 per pass)
+__global__ __launch_bounds__(kSortThreads) void morton_hist_kernel(
+    const float4 *__restrict__ posm, uint32_t n, const uint32_t *__restrict__ bound_bits,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, uint32_t *__restrict__ ghist) {
+    __shared__ uint32_t s_hist[8][256];
+    for (uint32_t p = 0; p < 8; ++p) s_hist[p][threadIdx.x] = 0;
+    __syncthreads();
+    const float root_w = __uint_as_float(*bound_bits) * 2.0f;  // root width, tree.rs:465
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t i = blockIdx.x * kSortTile + c * kSortThreads + threadIdx.x;
+        if (i >= n) break;
+        const float4 p = posm[i];
+        float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
+        uint64_t key = 0;
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) {
+#pragma clang fp contract(off)
+            const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
+            key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+            const float q = w / 4.0f;  // shift_node_center
+            cx = cx + (bx ? q : -q);
+            cy = cy + (by ? q : -q);
+            cz = cz + (bz ? q : -q);
+            w = w / 2.0f;
+        }
+        keys[i] = key;
+        idx[i] = i;
+#pragma unroll
+        for (uint32_t ps = 0; ps < 8; ++ps) atomicAdd(&s_hist[ps][(uint32_t)(key >> (8 * ps)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (uint32_t ps = 0; ps < 8; ++ps) {
+        const uint32_t v = s_hist[ps][threadIdx.x];
+        if (v) atomicAdd(&ghist[ps * 256 + threadIdx.x], v);
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void onesweep_kernel(
+    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
+    const uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_state, uint32_t *__restrict__ ticket,
+    uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_cnt[4][256];  // per-wave running digit counts -> exclusive wave offsets
+    __shared__ uint32_t s_base[256];    // global start of each digit + the tiles before this one
+    __shared__ uint32_t s_tile[256], s_w[4], s_w2[4], s_ticket;
+    __shared__ uint64_t s_key[kSortTile];
+    __shared__ uint32_t s_val[kSortTile];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    for (uint32_t w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_ticket;  // tiles are taken in launch order
+    const uint32_t base = tile * kSortTile + wave * (64 * kSortItems);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t key[kSortItems];
+    uint32_t val[kSortItems], local[kSortItems];
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t i = base + c * 64 + lane;
+        const bool valid = i < n;
+        key[c] = valid ? keys_in[i] : ~0ull;
+        val[c] = valid ? vals_in[i] : 0u;
+        const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+        uint64_t peers = __ballot(valid);  // lanes holding the same digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(peers & lt_mask);
+        const uint32_t before = valid ? s_cnt[wave][d] : 0u;  // same address for all peers
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) s_cnt[wave][d] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        local[c] = before + rank;
+    }
+    __syncthreads();
+    uint32_t tile_count;
+    {   // per digit: exclusive prefix over the 4 waves, and the digit's count in this tile
+        uint32_t o = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t t = s_cnt[w][threadIdx.x];
+            s_cnt[w][threadIdx.x] = o;
+            o += t;
+        }
+        tile_count = o;
+    }
+    // publish this tile's count of digit `threadIdx.x`, then look back for the tiles before it
+    uint32_t *my_state = tile_state + (size_t)tile * 256u + threadIdx.x;
+    __hip_atomic_store(my_state, tile_count | (tile == 0u ? kOsFlagInclusive : kOsFlagAggregate),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0u;
+    if (tile > 0u) {
+        uint32_t t = tile - 1u, spins = 0u;
+        for (;;) {
+            const uint32_t v = __hip_atomic_load(tile_state + (size_t)t * 256u + threadIdx.x, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 30) == 0u) {  // not published yet
+                if (++spins > kOsSpinLimit) {
+                    atomicAdd(&status[3], 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            excl += v & kOsValueMask;
+            if ((v >> 30) == 2u || t == 0u) break;
+            --t;
+        }
+        __hip_atomic_store(my_state, (excl + tile_count) | kOsFlagInclusive, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {   // where digit d starts globally: exclusive scan of the 256 digit totals (every block redoes it)
+        const uint32_t t = ghist[threadIdx.x];
+        uint32_t x = t;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+        s_base[threadIdx.x] = off + x - t + excl;
+    }
+    {   // where each digit's run starts inside the tile
+        uint32_t x = tile_count;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) s_w2[wave] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wave; ++w) off += s_w2[w];
+        s_tile[threadIdx.x] = off + x - tile_count;
+    }
+    __syncthreads();
+    // stage the tile in LDS in digit order, write it out as coalesced runs (as radix_scatter_kernel)
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t i = base + c * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+            const uint32_t pos = s_tile[d] + s_cnt[wave][d] + local[c];
+            s_key[pos] = key[c];
+            s_val[pos] = val[c];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile_n = min(kSortTile, n - tile * kSortTile);
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t j = c * kSortThreads + threadIdx.x;
+        if (j < tile_n) {
+            const uint64_t k = s_key[j];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t dst = s_base[d] + (j - s_tile[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_val[j];
+        }
+    }
+}
+
 // ---- 4. gather into sorted (DFS) order ----------------------------------------------------------
 // positions/masses first (the build needs them), velocities/accelerations separately (only the
 // walk needs them): on several GPUs the second pair is still being all-gathered while the build runs
@@ -1533,6 +1711,9 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&d_aos, sizeof(nb_particle) * nn)) return rc;
         if (int rc = alloc(&hist, sizeof(uint32_t) * 256 * (size_t)std::max(sort_blocks, id_blocks))) return rc;
         if (int rc = alloc(&totals, sizeof(uint32_t) * 256)) return rc;
+        // one-sweep sort: [8 x 256 digit histograms | 8 tickets (+ pad) | 8 x tiles x 256 look-back words]
+        os_words = 8 * 256 + 64 + 8 * (size_t)sort_blocks * 256;
+        if (int rc = alloc(&os_state, sizeof(uint32_t) * os_words)) return rc;
         if (int rc = alloc(&cpl, nn + 2)) return rc;
         if (int rc = alloc(&nint, sizeof(uint32_t) * nn)) return rc;
         if (int rc = alloc(&int_slot, sizeof(uint32_t) * nn)) return rc;
@@ -1928,10 +2109,24 @@ class TreeSim final : public SimBase {
             hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
                                bound_bits);
         }
+        int kb = 0;
+        if (sort_mode == 1) {
+            // 3b: keys + all digit histograms in one launch, then one launch per digit
+            const size_t words = 8 * 256 + 64 + 8 * (size_t)sort_blocks * 256;
+            NB_HIP_TRY(hipMemsetAsync(os_state, 0, sizeof(uint32_t) * words, stream));
+            hipLaunchKernelGGL(morton_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n,
+                               bound_bits, keys[0], idx[0], os_state);
+            for (uint32_t ps = 0; ps < 8; ++ps) {
+                hipLaunchKernelGGL(onesweep_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
+                                   idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, os_state + ps * 256,
+                                   os_state + 8 * 256 + 64 + (size_t)ps * sort_blocks * 256,
+                                   os_state + 8 * 256 + ps, status);
+                kb ^= 1;
+            }
+        } else {
         hipLaunchKernelGGL(morton_kernel, dim3(g256), b256, 0, stream, posm[s], n, bound_bits, keys[0],
                            idx[0]);
         // 3: sort (key, index) by key
-        int kb = 0;
         for (uint32_t shift = 0; shift < 63; shift += 8) {
             hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
                                n, shift, hist, sort_blocks);
@@ -1946,6 +2141,7 @@ class TreeSim final : public SimBase {
                                    sort_blocks);
             }
             kb ^= 1;
+        }
         }
         uint64_t *skeys = keys[kb];
         order = idx[kb];
@@ -2232,6 +2428,11 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: one launch per digit (look-back), 0: three
+            sort_mode = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_use_graph") == 0) {
             use_graph = value != 0;
             drop_graph();
@@ -2321,7 +2522,9 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
-    uint32_t walk_mode = 1, walk_group = 0;
+    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1;
+    uint32_t *os_state = nullptr;
+    size_t os_words = 0;
     bool build_done = false;  // phase 0 of the next step already enqueued
     // locally essential trees (section 9); let_world == 0: not in use
     int let_world = 0, let_rank = 0, let_next = 0;
