@@ -65,5 +65,5 @@ def test_cli_tree_against_oracle(gpu, oracle, tmp_path):
 
 
 def test_cli_reports_errors_with_a_status(gpu, tmp_path):
-    p = subprocess.run([CLI, "--sim", "tree", "--n", 64, "--bogus", 1], capture_output=True, text=True, timeout=60)
+    p = subprocess.run([CLI, "--sim", "tree", "--n", "64", "--bogus", "1"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "unknown option" in p.stderr

@@ -20,7 +20,7 @@ prev_end = None
 tot_busy = 0
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("nb::(anonymous namespace)::", "")[:48]
+    name = r["Kernel_Name"].replace("nb::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
     gap = (s - prev_end) / 1e3 if prev_end else 0.0
     print("%8.1f us  +%5.1f gap  %7.1f us  %s" % ((s - t0) / 1e3, gap, (e - s) / 1e3, name))
     prev_end = e

@@ -86,35 +86,68 @@ __global__ __launch_bounds__(256) void bound_kernel(const float4 *__restrict__ p
         atomicMax(bound_bits, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
+// The walk kernels also accumulate the NEXT step's bound from the positions they write (64 slots
+// to spread the atomics; a wave skips the atomic when its value is not above what it reads), so a
+// steady-state step needs neither bound_kernel nor a memset: morton_kernel takes the maximum.
+constexpr uint32_t kBoundSlots = 64;
+__device__ __forceinline__ void publish_bound(uint32_t *__restrict__ slots, uint32_t key, float m) {
+    uint32_t *slot = slots + (key & (kBoundSlots - 1u));
+    const uint32_t bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+
 // ---- 2. keys ------------------------------------------------------------------------------------
-__global__ void morton_kernel(const float4 *__restrict__ posm, uint32_t n,
-                              const uint32_t *__restrict__ bound_bits, uint64_t *__restrict__ keys,
-                              uint32_t *__restrict__ idx) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = posm[i];
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    float w = __uint_as_float(*bound_bits) * 2.0f;  // root width, tree.rs:465
-    uint64_t key = 0;
+// One workgroup per sort tile: the keys, and the tile's histogram of the first digit (saves the
+// first pass its histogram launch).
+// bound_src: where the root cube's half width comes from -- scalars[0] (bound_kernel / the LET
+// maximum; n_src = 1) or the kBoundSlots words accumulated by the previous step's walk (n_src =
+// kBoundSlots); it is republished in scalars[0].
+__global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__restrict__ posm, uint32_t n,
+                                                              const uint32_t *__restrict__ bound_src,
+                                                              uint32_t n_src, uint32_t *__restrict__ bound_bits,
+                                                              uint64_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ idx,
+                                                              uint32_t *__restrict__ hist, uint32_t nblocks) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t bmax = 0;
+    for (uint32_t k = 0; k < n_src; ++k) bmax = max(bmax, bound_src[k]);
+    const float bound = fmaxf(1.0f, __uint_as_float(bmax));  // never below 1.0, tree.rs:427-433
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bound_src != bound_bits) *bound_bits = __float_as_uint(bound);
+    const float root_w = bound * 2.0f;  // root width, tree.rs:465
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t i = blockIdx.x * kSortTile + c * kSortThreads + threadIdx.x;
+        if (i >= n) break;
+        const float4 p = posm[i];
+        float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
+        uint64_t key = 0;
 #pragma unroll
-    for (int l = 0; l < kLevels; ++l) {
+        for (int l = 0; l < kLevels; ++l) {
 #pragma clang fp contract(off)
-        const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
-        key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
-        const float q = w / 4.0f;  // shift_node_center
-        cx = cx + (bx ? q : -q);
-        cy = cy + (by ? q : -q);
-        cz = cz + (bz ? q : -q);
-        w = w / 2.0f;
+            const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
+            key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+            const float q = w / 4.0f;  // shift_node_center
+            cx = cx + (bx ? q : -q);
+            cy = cy + (by ? q : -q);
+            cz = cz + (bz ? q : -q);
+            w = w / 2.0f;
+        }
+        keys[i] = key;
+        idx[i] = i;
+        atomicAdd(&s_hist[(uint32_t)key & 255u], 1u);
     }
-    keys[i] = key;
-    idx[i] = i;
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];  // bin-major
 }
 
 // ---- 3. radix sort (LSD, 8-bit digits, pairs) ---------------------------------------------------
 // A block owns a tile of kSortTile elements; wave w owns the contiguous sub-range
 // [w*64*ITEMS, (w+1)*64*ITEMS) of it, read in ITEMS chunks of 64 -- so "wave, chunk, lane" order
 // IS the input order, which is what makes the per-wave ranking below stable.
+// (Counting the tile histograms of digit p + 1 inside the scatter of pass p, with one global atomic
+// per element where it lands, was measured and dropped: 47 instead of 12 us per scatter at 2^20
+// bodies, 10.8 instead of 5 + 5 at 8,192 -- profiles/r02_sort_experiments.txt.)
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t *__restrict__ hist,
     uint32_t nblocks) {
@@ -272,184 +305,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     __syncthreads();
     const uint32_t tile_n = min(kSortTile, n - blockIdx.x * kSortTile);
-#pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t j = c * kSortThreads + threadIdx.x;
-        if (j < tile_n) {
-            const uint64_t k = s_key[j];
-            const uint32_t d = (uint32_t)(k >> shift) & 255u;
-            const uint32_t dst = s_base[d] + (j - s_tile[d]);
-            keys_out[dst] = k;
-            vals_out[dst] = s_val[j];
-        }
-    }
-}
-
-// ---- 3b. one-sweep radix sort: ONE launch per 8-bit digit ------------------------------------------
-// The three-kernel pass above (tile histograms, per-bin scan over the tiles, scatter) is launch-bound
-// on the small problems and reads the keys twice.  Here the digit histograms of ALL eight passes are
-// taken once, while the keys are generated (a digit's global histogram does not depend on the order
-// of the keys), and a pass is a single kernel: a workgroup takes the next tile by ticket, counts its
-// digits, publishes the counts, and finds where its digits start by looking BACK over the tiles before
-// it (decoupled look-back: per tile and digit one word {flag, count} -- "aggregate" = this tile's
-// count, "inclusive" = count of this and all earlier tiles -- written and polled with agent-scope
-// atomics, since the tiles before it may run on another XCD).  Tickets are handed out in launch
-// order, so every tile a workgroup waits for is already running: no deadlock; the spin is bounded
-// all the same and reports through status[3] rather than hanging the GPU.
-constexpr uint32_t kOsFlagAggregate = 1u << 30, kOsFlagInclusive = 2u << 30, kOsValueMask = (1u << 30) - 1u;
-constexpr uint32_t kOsSpinLimit = 1u << 22;
-
-// keys as morton_kernel, plus the eight global digit histograms (bin-major rows of 256 per pass)
-__global__ __launch_bounds__(kSortThreads) void morton_hist_kernel(
-    const float4 *__restrict__ posm, uint32_t n, const uint32_t *__restrict__ bound_bits,
-    uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, uint32_t *__restrict__ ghist) {
-    __shared__ uint32_t s_hist[8][256];
-    for (uint32_t p = 0; p < 8; ++p) s_hist[p][threadIdx.x] = 0;
-    __syncthreads();
-    const float root_w = __uint_as_float(*bound_bits) * 2.0f;  // root width, tree.rs:465
-    for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = blockIdx.x * kSortTile + c * kSortThreads + threadIdx.x;
-        if (i >= n) break;
-        const float4 p = posm[i];
-        float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
-        uint64_t key = 0;
-#pragma unroll
-        for (int l = 0; l < kLevels; ++l) {
-#pragma clang fp contract(off)
-            const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
-            key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
-            const float q = w / 4.0f;  // shift_node_center
-            cx = cx + (bx ? q : -q);
-            cy = cy + (by ? q : -q);
-            cz = cz + (bz ? q : -q);
-            w = w / 2.0f;
-        }
-        keys[i] = key;
-        idx[i] = i;
-#pragma unroll
-        for (uint32_t ps = 0; ps < 8; ++ps) atomicAdd(&s_hist[ps][(uint32_t)(key >> (8 * ps)) & 255u], 1u);
-    }
-    __syncthreads();
-    for (uint32_t ps = 0; ps < 8; ++ps) {
-        const uint32_t v = s_hist[ps][threadIdx.x];
-        if (v) atomicAdd(&ghist[ps * 256 + threadIdx.x], v);
-    }
-}
-
-__global__ __launch_bounds__(kSortThreads) void onesweep_kernel(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
-    const uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_state, uint32_t *__restrict__ ticket,
-    uint32_t *__restrict__ status) {
-    __shared__ uint32_t s_cnt[4][256];  // per-wave running digit counts -> exclusive wave offsets
-    __shared__ uint32_t s_base[256];    // global start of each digit + the tiles before this one
-    __shared__ uint32_t s_tile[256], s_w[4], s_w2[4], s_ticket;
-    __shared__ uint64_t s_key[kSortTile];
-    __shared__ uint32_t s_val[kSortTile];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-    for (uint32_t w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t tile = s_ticket;  // tiles are taken in launch order
-    const uint32_t base = tile * kSortTile + wave * (64 * kSortItems);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint64_t key[kSortItems];
-    uint32_t val[kSortItems], local[kSortItems];
-#pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = base + c * 64 + lane;
-        const bool valid = i < n;
-        key[c] = valid ? keys_in[i] : ~0ull;
-        val[c] = valid ? vals_in[i] : 0u;
-        const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);  // lanes holding the same digit
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        const uint32_t rank = __popcll(peers & lt_mask);
-        const uint32_t before = valid ? s_cnt[wave][d] : 0u;  // same address for all peers
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) s_cnt[wave][d] = before + (uint32_t)__popcll(peers);
-        __builtin_amdgcn_wave_barrier();
-        local[c] = before + rank;
-    }
-    __syncthreads();
-    uint32_t tile_count;
-    {   // per digit: exclusive prefix over the 4 waves, and the digit's count in this tile
-        uint32_t o = 0;
-        for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t t = s_cnt[w][threadIdx.x];
-            s_cnt[w][threadIdx.x] = o;
-            o += t;
-        }
-        tile_count = o;
-    }
-    // publish this tile's count of digit `threadIdx.x`, then look back for the tiles before it
-    uint32_t *my_state = tile_state + (size_t)tile * 256u + threadIdx.x;
-    __hip_atomic_store(my_state, tile_count | (tile == 0u ? kOsFlagInclusive : kOsFlagAggregate),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0u;
-    if (tile > 0u) {
-        uint32_t t = tile - 1u, spins = 0u;
-        for (;;) {
-            const uint32_t v = __hip_atomic_load(tile_state + (size_t)t * 256u + threadIdx.x, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            if ((v >> 30) == 0u) {  // not published yet
-                if (++spins > kOsSpinLimit) {
-                    atomicAdd(&status[3], 1u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
-            excl += v & kOsValueMask;
-            if ((v >> 30) == 2u || t == 0u) break;
-            --t;
-        }
-        __hip_atomic_store(my_state, (excl + tile_count) | kOsFlagInclusive, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    {   // where digit d starts globally: exclusive scan of the 256 digit totals (every block redoes it)
-        const uint32_t t = ghist[threadIdx.x];
-        uint32_t x = t;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
-        }
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
-        s_base[threadIdx.x] = off + x - t + excl;
-    }
-    {   // where each digit's run starts inside the tile
-        uint32_t x = tile_count;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
-        }
-        if (lane == 63) s_w2[wave] = x;
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t w = 0; w < wave; ++w) off += s_w2[w];
-        s_tile[threadIdx.x] = off + x - tile_count;
-    }
-    __syncthreads();
-    // stage the tile in LDS in digit order, write it out as coalesced runs (as radix_scatter_kernel)
-#pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = base + c * 64 + lane;
-        if (i < n) {
-            const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-            const uint32_t pos = s_tile[d] + s_cnt[wave][d] + local[c];
-            s_key[pos] = key[c];
-            s_val[pos] = val[c];
-        }
-    }
-    __syncthreads();
-    const uint32_t tile_n = min(kSortTile, n - tile * kSortTile);
 #pragma unroll
     for (uint32_t c = 0; c < kSortItems; ++c) {
         const uint32_t j = c * kSortThreads + threadIdx.x;
@@ -743,6 +598,198 @@ __global__ __launch_bounds__(256) void moments_scan_kernel(const Moments *__rest
     }
 }
 
+// ---- 5b/6a fused: cells, node ids and moment prefixes in three launches --------------------------
+// The thirteen small kernels of sections 5 and 6a (cpl, three scans of nint, depth histogram + scan
+// + bases, ids, two moment passes + scan, and the gather of section 4) are one prefix computation
+// over the sorted bodies with a 28-word state: 1 count of opened cells, 23 per-depth node counts,
+// 4 binary64 moments.  A: per tile of 1,024 bodies, gather + cpl + the tile's totals.  B: ONE
+// workgroup scans the tiles' totals (fixed order: deterministic moments) and derives the depth
+// bases and the node count.  C: per tile, the bodies' own prefixes inside the tile + the tile's
+// offsets -> node ids, slots and moment prefixes.  Any number of tiles: no size cap.
+constexpr uint32_t kCellTile = 1024;                 // bodies per workgroup of A and C: 4 rounds of 256 (1 round
+                                                     // = 256 bodies on small problems, which are bound by the
+                                                     // chain of barriers inside a workgroup, not by work)
+constexpr uint32_t kCellRows = kMaxDepth + 2;        // u32 rows of the tile table: [0] nint, [1 + d] depth d
+
+__global__ __launch_bounds__(256) void cells_a_kernel(
+    const uint32_t *__restrict__ order, uint32_t n, const float4 *__restrict__ posm_in,
+    float4 *__restrict__ posm_out, const uint64_t *__restrict__ keys, int8_t *__restrict__ cpl,
+    uint32_t *__restrict__ tile_u32, Moments *__restrict__ tile_mom, uint32_t stride, uint32_t rounds,
+    uint32_t *__restrict__ status) {
+    __shared__ uint32_t s_hist[kCellRows];
+    __shared__ Moments s_wave[4];
+    if (threadIdx.x < kCellRows) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    Moments msum{0, 0, 0, 0};
+    uint32_t nint_sum = 0, collide = 0;
+    for (uint32_t sub = 0; sub < rounds; ++sub) {
+        const uint32_t k = (blockIdx.x * rounds + sub) * 256u + threadIdx.x;
+        Moments item{0, 0, 0, 0};
+        if (k < n) {
+            const float4 p = posm_in[order[k]];  // sort_particles, tree.rs:564-602
+            posm_out[k] = p;
+            const double m = (double)p.w;
+            item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
+            const uint64_t me = keys[k];
+            const int left = k > 0 ? cpl_levels(keys[k - 1], me) : -1;
+            const int right = k + 1 < n ? cpl_levels(me, keys[k + 1]) : -1;
+            if (k == 0) cpl[0] = -1;
+            cpl[k + 1] = (int8_t)right;
+            nint_sum += right > left ? (uint32_t)(right - left) : 0u;  // internal cells this body opens
+            for (int d = left + 1; d <= right; ++d) atomicAdd(&s_hist[1 + d], 1u);
+            atomicAdd(&s_hist[1 + (left > right ? left : right) + 1], 1u);  // its leaf
+            if (k + 1 < n && keys[k + 1] == me) collide += 1u;
+        }
+        Moments total;
+        (void)block_scan_moments(item, s_wave, &total);  // fixed order inside the round
+        msum = msum + total;
+    }
+    if (nint_sum) atomicAdd(&s_hist[0], nint_sum);
+    if (collide) atomicAdd(&status[2], collide);
+    __syncthreads();
+    if (threadIdx.x < kCellRows) tile_u32[(size_t)threadIdx.x * stride + blockIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x == 0) tile_mom[blockIdx.x] = msum;
+}
+
+// B: exclusive scan over the tiles of every row (one wave per row, lanes take contiguous segments)
+__global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__ tile_u32,
+                                                          Moments *__restrict__ tile_mom, uint32_t ntiles,
+                                                          uint32_t stride,
+                                                          uint32_t *__restrict__ depth_base,
+                                                          uint32_t *__restrict__ n_nodes, uint32_t cap,
+                                                          uint32_t *__restrict__ status,
+                                                          uint32_t *__restrict__ bound_slots) {
+    __shared__ uint32_t s_total[kCellRows];
+    if (threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // a wave takes a row in chunks of 256 tiles: every lane 4 consecutive tiles (one 16-byte
+    // access; rows are padded to a multiple of 4 words), a wave scan of the lane sums, a carry
+    for (uint32_t r = wave; r < kCellRows; r += 16u) {
+        uint4 *row = reinterpret_cast<uint4 *>(tile_u32 + (size_t)r * stride);
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < stride; base += 256u) {
+            const uint32_t i4 = base / 4u + lane;
+            uint4 v{0u, 0u, 0u, 0u};
+            if (i4 * 4u < stride) v = row[i4];
+            if (i4 * 4u + 0u >= ntiles) v.x = 0u;  // (the padding of the row was never written)
+            if (i4 * 4u + 1u >= ntiles) v.y = 0u;
+            if (i4 * 4u + 2u >= ntiles) v.z = 0u;
+            if (i4 * 4u + 3u >= ntiles) v.w = 0u;
+            const uint32_t sum = v.x + v.y + v.z + v.w;
+            uint32_t x = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o);
+                if ((int)lane >= o) x += y;
+            }
+            const uint32_t run = carry + x - sum;
+            if (i4 * 4u < stride) row[i4] = uint4{run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z};
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        }
+        if (lane == 0u) s_total[r] = carry;
+    }
+    const uint32_t seg = (ntiles + 63u) / 64u;
+    const uint32_t lo = min(lane * seg, ntiles), hi = min(lo + seg, ntiles);
+    if (wave == 15u) {  // the moments, strictly in tile order per lane segment, then in lane order
+        Moments sum{0, 0, 0, 0};
+        for (uint32_t i = lo; i < hi; ++i) sum = sum + tile_mom[i];
+        Moments x = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            Moments y{__shfl_up(x.x, o), __shfl_up(x.y, o), __shfl_up(x.z, o), __shfl_up(x.m, o)};
+            if ((int)lane >= o) x = x + y;
+        }
+        Moments run{x.x - sum.x, x.y - sum.y, x.z - sum.z, x.m - sum.m};
+        for (uint32_t i = lo; i < hi; ++i) {
+            const Moments v = tile_mom[i];
+            tile_mom[i] = run;
+            run = run + v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // depth_base[d] = nodes of depth < d; [kMaxDepth + 1] = node count
+        uint32_t run = 0;
+        for (int d = 0; d <= kMaxDepth; ++d) {
+            depth_base[d] = run;
+            run += s_total[1 + d];
+        }
+        depth_base[kMaxDepth + 1] = run;
+        *n_nodes = run;
+        if (run > cap) atomicAdd(&status[1], 1u);
+    }
+}
+
+// C: node ids (rank of (body k, depth d) among the nodes of depth d in key order = the reference's
+// BFS allocation order), slots of the opened cells, moment prefixes
+__global__ __launch_bounds__(256) void cells_c_kernel(
+    const int8_t *__restrict__ cpl, uint32_t n, const uint32_t *__restrict__ tile_u32,
+    const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ depth_base,
+    const float4 *__restrict__ posm, uint32_t *__restrict__ int_slot, uint32_t *__restrict__ leaf_id,
+    uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
+    Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds) {
+    __shared__ uint32_t s_cnt[4][kMaxDepth + 1], s_run[kMaxDepth + 1], s_scan[4];
+    __shared__ Moments s_wave[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (threadIdx.x <= kMaxDepth)  // where this tile's nodes of depth d start
+        s_run[threadIdx.x] = depth_base[threadIdx.x] + tile_u32[(size_t)(1 + threadIdx.x) * stride + blockIdx.x];
+    uint32_t slot_run = tile_u32[blockIdx.x];  // row 0: opened cells before this tile
+    Moments mom_run = tile_mom[blockIdx.x];
+    __syncthreads();
+    for (uint32_t sub = 0; sub < rounds; ++sub) {
+        const uint32_t k = (blockIdx.x * rounds + sub) * 256u + threadIdx.x;
+        const bool valid = k < n;
+        const int left = valid ? cpl[k] : 0, right = valid ? cpl[k + 1] : 0;
+        const int leafd = (left > right ? left : right) + 1;
+        uint32_t rank_in_wave[kMaxDepth + 1];
+#pragma unroll
+        for (int d = 0; d <= kMaxDepth; ++d) {
+            const bool st = valid && starts_node_at(left, right, d);
+            const uint64_t bal = __ballot(st);
+            rank_in_wave[d] = __popcll(bal & lt_mask);
+            if (lane == 0) s_cnt[wave][d] = (uint32_t)__popcll(bal);
+        }
+        const uint32_t ni = valid && right > left ? (uint32_t)(right - left) : 0u;
+        uint32_t ni_total;
+        const uint32_t slot0 = slot_run + block_exclusive_scan_256(ni, s_scan, &ni_total);  // (syncs)
+        Moments item{0, 0, 0, 0};
+        if (valid) {
+            const float4 p = posm[k];
+            const double m = (double)p.w;
+            item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
+        }
+        Moments mom_total;
+        const Moments mom0 = mom_run + block_scan_moments(item, s_wave, &mom_total);  // (syncs)
+        if (k <= n) prefix[k] = mom0;  // includes prefix[n] = the grand total
+        if (valid) {
+            int_slot[k] = slot0;
+#pragma unroll
+            for (int d = 0; d <= kMaxDepth; ++d) {
+                if (!starts_node_at(left, right, d)) continue;
+                uint32_t before = 0;
+                for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w][d];
+                const uint32_t id = s_run[d] + before + rank_in_wave[d];
+                if (d == leafd) {
+                    leaf_id[k] = id;
+                } else {
+                    // (a clustered input can open far more internal cells than the 4N capacity)
+                    const uint32_t slot = slot0 + (uint32_t)(d - left - 1);
+                    if (slot < cap) int_id[slot] = id;
+                }
+                if (id < cap) {
+                    node_first[id] = k;
+                    node_depth[id] = (uint8_t)(d | (d == leafd ? 0x80 : 0));
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x <= kMaxDepth)
+            s_run[threadIdx.x] += s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] +
+                                  s_cnt[3][threadIdx.x];
+        slot_run += ni_total;
+        mom_run = mom_run + mom_total;
+        __syncthreads();
+    }
+}
+
 // ---- 6. node contents ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t *keys, uint32_t lo, uint32_t hi,
                                                     uint64_t v) {  // first k in [lo,hi) with key >= v
@@ -929,7 +976,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
     WalkRoots roots,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt, float theta,
-    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
+    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ bound_slots) {
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -950,6 +998,11 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
+    if (bound_slots) {  // the next step's root cube: max |coord| of the new positions
+        float m = valid ? fmaxf(fabsf(xi), fmaxf(fabsf(yi), fabsf(zi))) : 0.f;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0u) publish_bound(bound_slots, blockIdx.x * 4u + wave, m);
+    }
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (PART == 2 && valid) {
         const float4 part = acc_dst[i];
@@ -1157,7 +1210,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
-    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters) {
+    uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ bound_slots) {
     __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1194,6 +1248,9 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
 #define NB_UNIFORM(x) x = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)))
     NB_UNIFORM(blx); NB_UNIFORM(bly); NB_UNIFORM(blz); NB_UNIFORM(bhx); NB_UNIFORM(bhy); NB_UNIFORM(bhz);
 #undef NB_UNIFORM
+    if (bound_slots && lane == 0u)  // the next step's root cube: max |coord| of the new positions
+        publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
+                                                     fmaxf(fabsf(blz), fabsf(bhz))));
     const float theta2 = theta * theta;
     const uint32_t root0 = roots.id[0];  // a record every idle lane may read
     const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
@@ -1691,12 +1748,7 @@ class TreeSim final : public SimBase {
         const size_t nn = n ? n : 1;
         node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
-        id_blocks = (uint32_t)((nn + kIdThreads - 1) / kIdThreads);
-        scan_blocks = (uint32_t)((nn + kScanTile - 1) / kScanTile);
-        if (scan_blocks > kScanTile) {
-            set_error("TreeSim supports at most %u bodies", kScanTile * kScanTile);
-            return NB_ERR_UNSUPPORTED;
-        }
+        cell_tiles = (uint32_t)(std::min<size_t>(nn, 131072) / 256 + (nn + 1 + kCellTile - 1) / kCellTile + 2);  // capacity
         const size_t npad = n_pad ? n_pad : 256;  // equal-sized slices for the all-gathers
         for (int b = 0; b < 2; ++b) {
             if (int rc = alloc(&posm[b], sizeof(float4) * npad)) return rc;
@@ -1709,36 +1761,27 @@ class TreeSim final : public SimBase {
             if (int rc = alloc(&idx[b], sizeof(uint32_t) * nn)) return rc;
         }
         if (int rc = alloc(&d_aos, sizeof(nb_particle) * nn)) return rc;
-        if (int rc = alloc(&hist, sizeof(uint32_t) * 256 * (size_t)std::max(sort_blocks, id_blocks))) return rc;
+        if (int rc = alloc(&hist, sizeof(uint32_t) * 256 * (size_t)sort_blocks)) return rc;
         if (int rc = alloc(&totals, sizeof(uint32_t) * 256)) return rc;
-        // one-sweep sort: [8 x 256 digit histograms | 8 tickets (+ pad) | 8 x tiles x 256 look-back words]
-        os_words = 8 * 256 + 64 + 8 * (size_t)sort_blocks * 256;
-        if (int rc = alloc(&os_state, sizeof(uint32_t) * os_words)) return rc;
         if (int rc = alloc(&cpl, nn + 2)) return rc;
-        if (int rc = alloc(&nint, sizeof(uint32_t) * nn)) return rc;
         if (int rc = alloc(&int_slot, sizeof(uint32_t) * nn)) return rc;
-        if (int rc = alloc(&scan_sums, sizeof(uint32_t) * (kScanTile + 8))) return rc;
-        if (int rc = alloc(&scan_sums2, sizeof(uint32_t) * (kScanTile + 8))) return rc;
+        if (int rc = alloc(&tile_u32, sizeof(uint32_t) * kCellRows * ((size_t)cell_tiles + 4))) return rc;
+        if (int rc = alloc(&tile_mom, sizeof(Moments) * (size_t)cell_tiles)) return rc;
         if (int rc = alloc(&leaf_id, sizeof(uint32_t) * nn)) return rc;
         if (int rc = alloc(&int_id, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_first, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_depth, (size_t)node_cap)) return rc;
-        if (int rc = alloc(&cogm, sizeof(float4) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&rec, sizeof(NodeRec) * (size_t)node_cap)) return rc;
-        mom_blocks = (uint32_t)((nn + 1 + kMomTile - 1) / kMomTile);  // covers prefix[n] too
-        if (int rc = alloc(&mom_sums, sizeof(Moments) * (size_t)mom_blocks)) return rc;
-        if (int rc = alloc(&mom_offsets, sizeof(Moments) * (size_t)mom_blocks)) return rc;
         if (int rc = alloc(&mom_prefix, sizeof(Moments) * (nn + 1))) return rc;
-        if (int rc = alloc(&bodies, sizeof(uint32_t) * (size_t)node_cap)) return rc;
-        if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
-        if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
-        if (int rc = alloc(&scalars, sizeof(uint32_t) * 64)) return rc;
+        // (the reference's Octant fields -- cogm, bodies, child, the AoS staging: 104 B per node -- are
+        // only produced for nb_sim_read_tree and allocated on its first call)
+        if (int rc = alloc(&scalars, sizeof(uint32_t) * 128)) return rc;
         #ifdef NB_DIAG_PHASES
         if (int rc = alloc(&counters, sizeof(unsigned long long) * (16 + nn + 8))) return rc;
 #else
         if (int rc = alloc(&counters, sizeof(unsigned long long) * 16)) return rc;
 #endif
-        NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 64, stream));
+        NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 128, stream));
         NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 16, stream));
         NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 4, hipHostMallocDefault));
         return write_particles(host, count);
@@ -1752,6 +1795,7 @@ class TreeSim final : public SimBase {
         if (int rc = bind_device()) return rc;
         if (n == 0) return NB_OK;
         build_done = false;  // a build enqueued for the old state is void
+        bound_from_walk = false;
         NB_HIP_TRY(hipMemcpyAsync(d_aos, host, sizeof(nb_particle) * (size_t)n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(tree_aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_aos, n,
                            posm[cur], vel[cur], acc[cur]);
@@ -2028,9 +2072,6 @@ class TreeSim final : public SimBase {
         params.particle_num = count;
         const size_t nn = n ? n : 1;
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
-        id_blocks = (uint32_t)((nn + kIdThreads - 1) / kIdThreads);
-        scan_blocks = (uint32_t)((nn + kScanTile - 1) / kScanTile);
-        mom_blocks = (uint32_t)((nn + 1 + kMomTile - 1) / kMomTile);
     }
 
     int let_set_imports(const uint32_t *counts, int world) override {
@@ -2099,77 +2140,61 @@ class TreeSim final : public SimBase {
     int enqueue_build(bool external_bound) {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
-        uint32_t *zero_word = scalars + 8;    // stays 0
         uint32_t *depth_base = scalars + 16;  // kMaxDepth + 2 entries
+        uint32_t *bound_slots = scalars + 64; // kBoundSlots words: the next bound, from the walk
         const dim3 b256(256);
         const uint32_t g256 = (n + 255) / 256;
         // 1-2: bound + keys from the step's source positions (old positions, tree.rs:290-295)
+        const uint32_t *bound_src = bound_bits;
+        uint32_t n_src = 1;
         if (!external_bound) {
-            NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));  // status words are sticky
-            hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
-                               bound_bits);
-        }
-        int kb = 0;
-        if (sort_mode == 1) {
-            // 3b: keys + all digit histograms in one launch, then one launch per digit
-            const size_t words = 8 * 256 + 64 + 8 * (size_t)sort_blocks * 256;
-            NB_HIP_TRY(hipMemsetAsync(os_state, 0, sizeof(uint32_t) * words, stream));
-            hipLaunchKernelGGL(morton_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n,
-                               bound_bits, keys[0], idx[0], os_state);
-            for (uint32_t ps = 0; ps < 8; ++ps) {
-                hipLaunchKernelGGL(onesweep_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
-                                   idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, os_state + ps * 256,
-                                   os_state + 8 * 256 + 64 + (size_t)ps * sort_blocks * 256,
-                                   os_state + 8 * 256 + ps, status);
-                kb ^= 1;
+            if (bound_from_walk) {  // the previous step's walk has already taken max |coord| of this state
+                bound_src = bound_slots;
+                n_src = kBoundSlots;
+            } else {
+                NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));  // status words are sticky
+                hipLaunchKernelGGL(bound_kernel, dim3(std::min<uint32_t>(g256, 512)), b256, 0, stream, posm[s], n,
+                                   bound_bits);
             }
-        } else {
-        hipLaunchKernelGGL(morton_kernel, dim3(g256), b256, 0, stream, posm[s], n, bound_bits, keys[0],
-                           idx[0]);
-        // 3: sort (key, index) by key
-        for (uint32_t shift = 0; shift < 63; shift += 8) {
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
-                               n, shift, hist, sort_blocks);
+        }
+        bound_from_walk = false;
+        hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
+                           n_src, bound_bits, keys[0], idx[0], hist, sort_blocks);
+        // 3: sort (key, index) by key: 8 passes of 8 bits
+        int kb = 0;
+        for (uint32_t ps = 0; ps < 8; ++ps) {
+            if (ps)  // (the first digit's tile histograms come with the keys)
+                hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
+                                   n, 8u * ps, hist, sort_blocks);
             if (sort_blocks <= kSortInlineScanBlocks) {
                 hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
+                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
                                    sort_blocks);
             } else {
                 hipLaunchKernelGGL(bin_scan_kernel, dim3(256), b256, 0, stream, hist, sort_blocks, totals);
                 hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
+                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
                                    sort_blocks);
             }
             kb ^= 1;
         }
-        }
         uint64_t *skeys = keys[kb];
         order = idx[kb];
-        // 4: the step's source, permuted into DFS/Morton order (tree.rs:297,315-325)
-        hipLaunchKernelGGL(gather_posm_kernel, dim3(g256), b256, 0, stream, order, n, posm[s], posm[d]);
-        // 5: cells -> node ids
-        hipLaunchKernelGGL(cpl_kernel, dim3(g256), b256, 0, stream, skeys, n, cpl, nint, status);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(scan_blocks), b256, 0, stream, nint, n, scan_sums);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(1), b256, 0, stream, scan_sums, scan_blocks,
-                           zero_word, scan_sums2, (uint32_t *)nullptr);  // <= 2048 block sums: one tile
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(scan_blocks), b256, 0, stream, nint, n, scan_sums2,
-                           int_slot, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(depth_hist_kernel, dim3(id_blocks), dim3(kIdThreads), 0, stream, cpl, n, hist,
-                           id_blocks);
-        hipLaunchKernelGGL(bin_scan_kernel, dim3(kMaxDepth + 1), b256, 0, stream, hist, id_blocks, totals);
-        hipLaunchKernelGGL(depth_base_kernel, dim3(1), dim3(1), 0, stream, totals, depth_base, n_nodes,
-                           node_cap, status);
-        hipLaunchKernelGGL(assign_ids_kernel, dim3(id_blocks), dim3(kIdThreads), 0, stream, cpl, n, hist,
-                           id_blocks, depth_base, int_slot, leaf_id, int_id, node_first, node_depth,
-                           node_cap);
-        // 6: mass moments by binary64 prefix sums over the sorted bodies, then node contents
-        hipLaunchKernelGGL(moments_kernel, dim3(mom_blocks), b256, 0, stream, posm[d], n, mom_sums,
-                           (const Moments *)nullptr, (Moments *)nullptr);
-        hipLaunchKernelGGL(moments_scan_kernel, dim3(1), b256, 0, stream, mom_sums, mom_blocks, mom_offsets);
-        hipLaunchKernelGGL(moments_kernel, dim3(mom_blocks), b256, 0, stream, posm[d], n,
-                           (Moments *)nullptr, mom_offsets, mom_prefix);
-        const uint32_t gnodes = (node_cap + 255) / 256;
         sorted_keys = skeys;
+        // 4-6a: the step's source permuted into DFS/Morton order (tree.rs:297,315-325), cells from
+        // key prefixes, node ids, moment prefixes: A, B, C of section 5b
+        const uint32_t rounds = n <= 131072u ? 1u : kCellTile / 256u;
+        const uint32_t ct = (uint32_t)(((size_t)n + 1 + 256 * rounds - 1) / (256 * rounds));  // covers prefix[n] too
+        const uint32_t cstride = (ct + 3u) & ~3u;  // rows of the tile table, padded to 16 bytes
+        hipLaunchKernelGGL(cells_a_kernel, dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys, cpl,
+                           tile_u32, tile_mom, cstride, rounds, status);
+        hipLaunchKernelGGL(cells_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
+                           depth_base, n_nodes, node_cap, status, bound_slots);
+        hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, depth_base,
+                           posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
+                           rounds);
+        // 6: node contents
+        const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel<false>, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                            node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
                            mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
@@ -2185,7 +2210,10 @@ class TreeSim final : public SimBase {
         if (part != 2)
             hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
                                vel[d], acc[d]);
-        // 8: walk + integrate: sorted source (now in buffer d) -> buffer s
+        // 8: walk + integrate: sorted source (now in buffer d) -> buffer s.  A walk over the whole state in
+        // one launch also leaves max |coord| of the new positions for the next step's root cube.
+        const bool whole = part == 0 && !let_world && place.world == 1 && lo == 0 && hi == n;
+        uint32_t *bslots = whole ? scalars + 64 : nullptr;
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo && walk_mode == 0) {
             // bodies per wave: 64 when that still gives >= 4096 waves (4 per SIMD), else halve down to 8
@@ -2200,7 +2228,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(COUNT, PART)                                                                              \
     hipLaunchKernelGGL((walk_kernel<COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,  \
                        roots, posm[s], vel[s], acc[s], lo, hi, shift, params.g, params.e, params.dt,      \
-                       theta, status, counters)
+                       theta, status, counters, bslots)
             if (count_visits) {
                 if (part == 0) NB_WALK(true, 0); else if (part == 1) NB_WALK(true, 1); else NB_WALK(true, 2);
             } else {
@@ -2215,7 +2243,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(G, COUNT, PART)                                                                               \
     hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, bwalk, 0, stream, posm[d], vel[d], acc[d],  \
                        rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt,     \
-                       theta, status, counters)
+                       theta, status, counters, bslots)
 #define NB_WALK_P(G, COUNT)                                                                   \
     do {                                                                                      \
         if (part == 0) NB_WALK(G, COUNT, 0); else if (part == 1) NB_WALK(G, COUNT, 1); else NB_WALK(G, COUNT, 2); \
@@ -2233,6 +2261,7 @@ class TreeSim final : public SimBase {
         }
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[1], stream));
         NB_HIP_TRY(hipGetLastError());
+        bound_from_walk = whole && hi > lo;
         // the post-step state is in buffer s (= cur); buffer d holds the sorted source
         return NB_OK;
     }
@@ -2311,6 +2340,12 @@ class TreeSim final : public SimBase {
         if (n_nodes_out) *n_nodes_out = nodes;
         const size_t m = std::min<size_t>(nodes, cap);
         if (m && dst) {
+            if (!d_tree_aos) {  // first read-back: the reference's Octant fields, 104 B per node
+                if (int rc = alloc(&cogm, sizeof(float4) * (size_t)node_cap)) return rc;
+                if (int rc = alloc(&bodies, sizeof(uint32_t) * (size_t)node_cap)) return rc;
+                if (int rc = alloc(&child, sizeof(uint32_t) * 8 * (size_t)node_cap)) return rc;
+                if (int rc = alloc(&d_tree_aos, sizeof(nb_octant) * (size_t)node_cap)) return rc;
+            }
             // the Octant fields are produced on demand from the step's build arrays, which stay
             // intact until the next step (buffer cur^1 holds the sorted source the tree was built on)
             hipLaunchKernelGGL(fill_kernel<true>, dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
@@ -2428,7 +2463,7 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
-        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: one launch per digit (look-back), 0: three
+        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: small problems one launch per digit, 0: always 2-3
             sort_mode = value != 0 ? 1u : 0u;
             drop_graph();
             return NB_OK;
@@ -2509,22 +2544,23 @@ class TreeSim final : public SimBase {
     uint64_t *sorted_keys = nullptr;  // of the last build
     nb_particle *d_aos = nullptr;
     nb_octant *d_tree_aos = nullptr;
-    uint32_t *hist = nullptr, *totals = nullptr, *nint = nullptr, *int_slot = nullptr;
-    uint32_t *scan_sums = nullptr, *scan_sums2 = nullptr, *leaf_id = nullptr, *int_id = nullptr;
+    uint32_t *hist = nullptr, *totals = nullptr, *int_slot = nullptr;
+    uint32_t *leaf_id = nullptr, *int_id = nullptr;
     uint32_t *node_first = nullptr, *bodies = nullptr, *child = nullptr, *scalars = nullptr;
     uint8_t *node_depth = nullptr;
     int8_t *cpl = nullptr;
     float4 *cogm = nullptr;
     NodeRec *rec = nullptr;  // per node: cogm + {first child id, child count} / leaf {sorted position, 0}
-    Moments *mom_sums = nullptr, *mom_offsets = nullptr, *mom_prefix = nullptr;
-    uint32_t mom_blocks = 0;
+    Moments *mom_prefix = nullptr;
     unsigned long long *counters = nullptr;
-    uint32_t node_cap = 0, sort_blocks = 0, id_blocks = 0, scan_blocks = 0;
+    uint32_t node_cap = 0, sort_blocks = 0;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1;
-    uint32_t *os_state = nullptr;
-    size_t os_words = 0;
+    uint32_t *tile_u32 = nullptr;
+    bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
+    Moments *tile_mom = nullptr;
+    uint32_t cell_tiles = 0;
     bool build_done = false;  // phase 0 of the next step already enqueued
     // locally essential trees (section 9); let_world == 0: not in use
     int let_world = 0, let_rank = 0, let_next = 0;
