@@ -7,34 +7,33 @@
 // then dispatches the walk.  Here the same tree -- same cells, same node numbering, same
 // children tables, same body order -- is constructed on the device from Morton keys:
 //
-//   1 bound_kernel        max |coord| (>= 1.0)  -> root cube [-b,b]^3           tree.rs:424-446
+//   1 bound               max |coord| (>= 1.0) -> root cube [-b,b]^3              tree.rs:424-446
+//                         (bound_kernel; in steady state accumulated by the previous step's walk)
 //   2 morton_kernel       63-bit key per body by the reference's own float descent:
 //                         digit = (x>cx) | (y>cy)<<1 | (z>cz)<<2 with strict '>',
 //                         centre += +-width/4, width /= 2   (21 levels)        tree.rs:549-562
-//   3 radix sort          8 passes x 8 bits, (key, index) pairs: per-block digit histogram in
-//                         LDS, per-bin scan, stable scatter ranked with wave ballots
-//   4 gather_kernel       bodies into sorted order = the reference's DFS order  tree.rs:564-602
-//   5 cpl/emit/ids        a cell at depth d exists for every key-prefix run; body k opens the
+//   3 radix sort          8 passes x 8 bits, (key, index) pairs: per-tile digit histogram in
+//                         LDS, per-bin scan over the tiles, stable scatter ranked with wave ballots
+//   4-6a cells_a/scan/c   bodies into sorted order = the reference's DFS order (tree.rs:564-602);
+//                         a cell at depth d exists for every key-prefix run: body k opens the
 //                         internal cells of depths (cpl[k-1], cpl[k]] and owns one leaf at depth
 //                         max(cpl[k-1],cpl[k])+1, where cpl = common prefix length (levels) of
 //                         neighbouring keys.  Node id = (#nodes of smaller depth) + rank among
 //                         the nodes of its depth in key order -- exactly the reference's BFS
-//                         allocation order (tree.rs:461,517-519; slice_alloc.rs:52-59).
+//                         allocation order (tree.rs:461,517-519; slice_alloc.rs:52-59); binary64
+//                         prefix sums of (m x, m y, m z, m) over the sorted bodies for the mass /
+//                         centre of gravity of every cell (tree.rs:486-505).  Three launches.
 //   6 fill_kernel         per node: body range by a galloping search on the keys; children = the
 //                         consecutive next-depth ids starting at the first body's own child
 //                         (0 = none; a leaf's children[0] = the body's source index, tree.rs:532)
-//   7 moments_kernel      mass / centre of gravity of every cell from binary64 prefix sums of
-//                         (m x, m y, m z, m) over the sorted bodies             tree.rs:486-505
-//   8 walk_kernel         tree.wgsl:41-111 with the INTENDED semantics: self
-//                         excluded by identity, a leaf is a body, no fixed 64-entry stack.
-//                         One wave walks for 64 consecutive (spatially coherent) bodies with a
-//                         wave-level stack of (node, lane mask) in LDS: a node is fetched once
-//                         per wave (wave-uniform address), every lane applies its OWN acceptance
-//                         test size/dist < theta, and children are pushed 0..7 for the lanes
-//                         that opened the node -- so each lane accumulates exactly the nodes of
-//                         the reference's per-thread walk (visit counts equal the oracle's).  Up
-//                         to four cells are popped and fetched per iteration, so the ORDER of a
-//                         lane's sum is not the reference's depth-first order (fp32 rounding).
+//   8 walk                tree.wgsl:41-111 with the INTENDED semantics: self
+//                         excluded by identity, a leaf is a body, no fixed 64-entry stack; every
+//                         body applies ITS OWN acceptance test size/dist < theta to exactly the
+//                         cells of the reference's per-thread walk (visit counts equal the
+//                         oracle's), in a different order of summation (fp32 rounding).
+//                         8b walk_cells_kernel (default): a wave walks for 8 bodies held in
+//                         scalars, its 64 lanes hold 64 cells of the traversal frontier.
+//                         8  walk_kernel: a wave walks for 64 bodies, one cell at a time.
 //
 // Deviations, all documented in DESIGN.md: bodies whose 63-bit keys collide (closer than
 // root_width/2^21) cannot be separated (the reference would recurse until its 4N-node buffer
@@ -53,7 +52,6 @@ constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
 constexpr uint32_t kSortInlineScanBlocks = 16;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
-constexpr uint32_t kIdThreads = 256;
 // wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
 // most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
 constexpr uint32_t kWalkStack = 192;
@@ -321,13 +319,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 // ---- 4. gather into sorted (DFS) order ----------------------------------------------------------
 // positions/masses first (the build needs them), velocities/accelerations separately (only the
 // walk needs them): on several GPUs the second pair is still being all-gathered while the build runs
-__global__ void gather_posm_kernel(const uint32_t *__restrict__ order, uint32_t n,
-                                   const float4 *__restrict__ posm_in, float4 *__restrict__ posm_out) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    posm_out[k] = posm_in[order[k]];
-}
-
 __global__ void gather_va_kernel(const uint32_t *__restrict__ order, uint32_t n,
                                  const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in,
                                  float4 *__restrict__ vel_out, float4 *__restrict__ acc_out) {
@@ -348,22 +339,7 @@ __device__ __forceinline__ int cpl_levels(uint64_t a, uint64_t b) {
     return lead / 3;
 }
 
-// cpl[k] for k in [-1, n-1] stored at cpl[k+1]: common prefix of keys k and k+1 (-1 at the ends).
-__global__ void cpl_kernel(const uint64_t *__restrict__ keys, uint32_t n, int8_t *__restrict__ cpl,
-                           uint32_t *__restrict__ nint, uint32_t *__restrict__ status) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint64_t me = keys[k];
-    const int left = k > 0 ? cpl_levels(keys[k - 1], me) : -1;
-    const int right = k + 1 < n ? cpl_levels(me, keys[k + 1]) : -1;
-    if (k == 0) cpl[0] = -1;
-    cpl[k + 1] = (int8_t)right;
-    nint[k] = right > left ? (uint32_t)(right - left) : 0u;  // internal cells this body opens
-    if (k + 1 < n && keys[k + 1] == me) atomicAdd(&status[2], 1u);
-}
-
-// three-kernel exclusive scan of u32 (block sums -> scan of sums -> local scan + offset)
-constexpr uint32_t kScanTile = 2048;
+// exclusive scan of one value per thread over a 256-thread workgroup
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *s_wave,
                                                              uint32_t *total) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -381,127 +357,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return off + x - v;
 }
 
-__global__ __launch_bounds__(256) void scan_sums_kernel(const uint32_t *__restrict__ in, uint32_t n,
-                                                        uint32_t *__restrict__ sums) {
-    __shared__ uint32_t s_wave[4];
-    uint32_t v = 0;
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j)
-        if (base + j < n) v += in[base + j];
-    uint32_t total;
-    (void)block_exclusive_scan_256(v, s_wave, &total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t n,
-                                                         const uint32_t *__restrict__ sums,
-                                                         uint32_t *__restrict__ out,
-                                                         uint32_t *__restrict__ grand_total) {
-    __shared__ uint32_t s_wave[4];
-    uint32_t item[8], v = 0;
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-        item[j] = base + j < n ? in[base + j] : 0u;
-        v += item[j];
-    }
-    uint32_t run = sums[blockIdx.x] + block_exclusive_scan_256(v, s_wave, nullptr);
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
-        if (base + j < n) out[base + j] = run;
-        run += item[j];
-    }
-    if (grand_total && base <= n - 1 && n - 1 < base + 8) *grand_total = run;
-}
-
 // depth of the cells body k opens / owns
 __device__ __forceinline__ bool starts_node_at(int left, int right, int d) {
     const bool internal = d > left && d <= right;           // first body of a >=2-body cell
     const bool leaf = d == (left > right ? left : right) + 1;  // alone from this depth on
     return internal || leaf;
-}
-
-// per-block count of nodes of every depth (22 bins), bin-major like the sort histograms
-__global__ __launch_bounds__(kIdThreads) void depth_hist_kernel(const int8_t *__restrict__ cpl,
-                                                                uint32_t n,
-                                                                uint32_t *__restrict__ hist,
-                                                                uint32_t nblocks) {
-    __shared__ uint32_t s_hist[kMaxDepth + 1];
-    if (threadIdx.x <= kMaxDepth) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t k = blockIdx.x * kIdThreads + threadIdx.x;
-    if (k < n) {
-        const int left = cpl[k], right = cpl[k + 1];
-        for (int d = left + 1; d <= right; ++d) atomicAdd(&s_hist[d], 1u);
-        atomicAdd(&s_hist[(left > right ? left : right) + 1], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x <= kMaxDepth) hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];
-}
-
-// depth_base[d] = number of nodes of depth < d; depth_base[kMaxDepth+1] = node count
-__global__ void depth_base_kernel(const uint32_t *__restrict__ totals, uint32_t *depth_base,
-                                  uint32_t *n_nodes, uint32_t cap, uint32_t *status) {
-    uint32_t run = 0;
-    for (int d = 0; d <= kMaxDepth; ++d) {
-        depth_base[d] = run;
-        run += totals[d];
-    }
-    depth_base[kMaxDepth + 1] = run;
-    *n_nodes = run;
-    if (run > cap) atomicAdd(&status[1], 1u);
-}
-
-// node ids: rank of (body k, depth d) among the nodes of depth d, in key order
-__global__ __launch_bounds__(kIdThreads) void assign_ids_kernel(
-    const int8_t *__restrict__ cpl, uint32_t n, const uint32_t *__restrict__ hist, uint32_t nblocks,
-    const uint32_t *__restrict__ depth_base, const uint32_t *__restrict__ int_slot,
-    uint32_t *__restrict__ leaf_id, uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first,
-    uint8_t *__restrict__ node_depth, uint32_t cap) {
-    __shared__ uint32_t s_cnt[4][kMaxDepth + 1];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t k = blockIdx.x * kIdThreads + threadIdx.x;
-    const bool valid = k < n;
-    const int left = valid ? cpl[k] : 0, right = valid ? cpl[k + 1] : 0;
-    const int leafd = (left > right ? left : right) + 1;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t rank_in_wave[kMaxDepth + 1];
-#pragma unroll
-    for (int d = 0; d <= kMaxDepth; ++d) {
-        const bool s = valid && starts_node_at(left, right, d);
-        const uint64_t bal = __ballot(s);
-        rank_in_wave[d] = __popcll(bal & lt_mask);
-        if (lane == 0) s_cnt[wave][d] = (uint32_t)__popcll(bal);
-    }
-    __syncthreads();
-    if (threadIdx.x <= kMaxDepth) {  // exclusive prefix over the 4 waves
-        uint32_t o = 0;
-        for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t t = s_cnt[w][threadIdx.x];
-            s_cnt[w][threadIdx.x] = o;
-            o += t;
-        }
-    }
-    __syncthreads();
-    if (!valid) return;
-#pragma unroll
-    for (int d = 0; d <= kMaxDepth; ++d) {
-        if (!starts_node_at(left, right, d)) continue;
-        const uint32_t id = depth_base[d] + hist[d * nblocks + blockIdx.x] + s_cnt[wave][d] +
-                            rank_in_wave[d];
-        if (d == leafd) {
-            leaf_id[k] = id;
-        } else {
-            // (a clustered input can open far more internal cells than the 4N capacity)
-            const uint32_t slot = int_slot[k] + (uint32_t)(d - left - 1);
-            if (slot < cap) int_id[slot] = id;
-        }
-        if (id < cap) {
-            node_first[id] = k;
-            node_depth[id] = (uint8_t)(d | (d == leafd ? 0x80 : 0));
-        }
-    }
 }
 
 // What the walk reads per cell, in one 32-byte scalar load: centre of gravity + mass, and the
@@ -527,8 +387,6 @@ struct Moments {
 __device__ __forceinline__ Moments operator+(const Moments &a, const Moments &b) {
     return Moments{a.x + b.x, a.y + b.y, a.z + b.z, a.m + b.m};
 }
-constexpr uint32_t kMomTile = 1024;  // bodies per block (256 threads x 4)
-
 __device__ __forceinline__ Moments block_scan_moments(Moments v, Moments *s_wave, Moments *total) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     Moments x = v;
@@ -545,62 +403,9 @@ __device__ __forceinline__ Moments block_scan_moments(Moments v, Moments *s_wave
     return Moments{off.x + x.x - v.x, off.y + x.y - v.y, off.z + x.z - v.z, off.m + x.m - v.m};
 }
 
-// pass 1 (sums != nullptr): per-block totals.  pass 2: prefix[k] for every body and prefix[n].
-__global__ __launch_bounds__(256) void moments_kernel(const float4 *__restrict__ posm, uint32_t n,
-                                                      Moments *__restrict__ block_sums,
-                                                      const Moments *__restrict__ block_offsets,
-                                                      Moments *__restrict__ prefix) {
-    __shared__ Moments s_wave[4];
-    Moments item[4], v{0, 0, 0, 0};
-    const uint32_t base = blockIdx.x * kMomTile + threadIdx.x * 4;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        if (base + j < n) {
-            const float4 p = posm[base + j];
-            const double m = (double)p.w;
-            item[j] = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
-        } else {
-            item[j] = Moments{0, 0, 0, 0};
-        }
-        v = v + item[j];
-    }
-    Moments total;
-    Moments run = block_scan_moments(v, s_wave, &total);
-    if (!prefix) {
-        if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-        return;
-    }
-    run = run + block_offsets[blockIdx.x];
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        if (base + j <= n) prefix[base + j] = run;  // includes prefix[n] = grand total
-        run = run + item[j];
-    }
-}
-
-// exclusive scan of the (<= 4096) block totals, one workgroup
-__global__ __launch_bounds__(256) void moments_scan_kernel(const Moments *__restrict__ sums,
-                                                           uint32_t nblocks,
-                                                           Moments *__restrict__ offsets) {
-    __shared__ Moments s_wave[4];
-    __shared__ Moments s_carry;
-    if (threadIdx.x == 0) s_carry = Moments{0, 0, 0, 0};
-    __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        const Moments v = i < nblocks ? sums[i] : Moments{0, 0, 0, 0};
-        Moments total;
-        const Moments ex = block_scan_moments(v, s_wave, &total);
-        if (i < nblocks) offsets[i] = ex + s_carry;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = s_carry + total;
-        __syncthreads();
-    }
-}
-
 // ---- 5b/6a fused: cells, node ids and moment prefixes in three launches --------------------------
-// The thirteen small kernels of sections 5 and 6a (cpl, three scans of nint, depth histogram + scan
-// + bases, ids, two moment passes + scan, and the gather of section 4) are one prefix computation
+// Round 1 ran this as thirteen small kernels (gather, cpl, three scans of the opened-cell counts,
+// depth histogram + scan + bases, ids, two moment passes + scan); it is one prefix computation
 // over the sorted bodies with a 28-word state: 1 count of opened cells, 23 per-depth node counts,
 // 4 binary64 moments.  A: per tile of 1,024 bodies, gather + cpl + the tile's totals.  B: ONE
 // workgroup scans the tiles' totals (fixed order: deterministic moments) and derives the depth
