@@ -312,6 +312,21 @@ typedef struct nb_runner nb_runner;
 int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
                      const nb_add_params *add_params, nb_init_fn init, void *user, int device_id);
 
+/* The same constructor over SEVERAL GPUs of this process (no reference counterpart: the reference
+ * owns one adapter, offline_headless.rs:22-31; this is SURVEY 8(b)'s `device_ids, n_devices` form).
+ * All-pairs only: rank r owns the contiguous body range [r per, (r+1) per), per =
+ * nb_shard_bodies_per_rank(N, n_devices), on device_ids[r]; every device keeps both position/mass
+ * buffers in full, and the kernel that finishes a rank's step stores the rank's new
+ * float4{x,y,z,m} slice into every peer's next-step buffer through peer access (one slice per
+ * xGMI link), ordered by one HIP event per rank and step -- no host copy, no collective library.
+ * One host thread per rank inside the library; the caller stays single-threaded and every call
+ * below is synchronous as on one device.  A device id may repeat (ranks sharing a GPU).  n_devices
+ * == 1 is nb_runner_create.  NB_ERR_UNSUPPORTED for a TreeSim: several-GPU Barnes-Hut runs one
+ * process per GPU (nb_placement, NB_PHASE_LET_*). */
+int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params,
+                           const nb_add_params *add_params, nb_init_fn init, void *user,
+                           const int *device_ids, int n_devices);
+
 /* `OfflineHeadless::step(&mut self)`, offline_headless.rs:38-44:
  * encode -> submit -> cleanup -> blocking wait. */
 int nb_runner_step(nb_runner *runner);
@@ -321,7 +336,8 @@ int nb_runner_step_n(nb_runner *runner, int n);
 
 int nb_runner_read_particles(nb_runner *runner, nb_particle *dst, size_t n);
 int nb_runner_sim_params(const nb_runner *runner, nb_sim_params *out);
-/* Borrow the runner's simulator (owned by the runner). */
+int nb_runner_step_num(const nb_runner *runner, uint64_t *out);
+/* Borrow the runner's simulator (owned by the runner); NULL for a several-GPU runner. */
 nb_sim *nb_runner_sim(nb_runner *runner);
 int nb_runner_destroy(nb_runner *runner);
 

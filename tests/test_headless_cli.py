@@ -67,3 +67,73 @@ def test_cli_tree_against_oracle(gpu, oracle, tmp_path):
 def test_cli_reports_errors_with_a_status(gpu, tmp_path):
     p = subprocess.run([CLI, "--sim", "tree", "--n", "64", "--bogus", "1"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "unknown option" in p.stderr
+
+
+# ---- several GPUs of one process behind the C ABI (nb_runner_create_multi), SURVEY 8(b)/(e) ----------
+
+def test_cli_eight_ranks_through_the_c_abi(gpu, oracle, tmp_path):
+    """BASELINE configs[1]'s 65,536 bodies stepped by the C++ host (no Python, no torch in the step
+    loop) as 8 ranks -- body ranges, every rank's new float4 slice stored straight into the peers'
+    next-step buffers by the finish kernel, one event per rank and step.  The 8 'devices' are this
+    box's one GPU eight times: the same code path as eight GPUs, minus the links.  Against the
+    one-device run of the same CLI and against the oracle on windows of bodies."""
+    from wgpu_n_body_amd.snapshot import load_snapshot
+    nb = gpu
+    n, steps = 65536, 3
+    common = ["--sim", "naive", "--n", n, "--init", "uniform", "--seed", 2, "--steps", steps]
+    os.makedirs(os.path.join(tmp_path, "multi"))
+    os.makedirs(os.path.join(tmp_path, "single"))
+    text, path8 = run_cli(common + ["--devices", "0,0,0,0,0,0,0,0"], os.path.join(tmp_path, "multi"))
+    assert text.count("Step Duration: ") == steps
+    _t, path1 = run_cli(common, os.path.join(tmp_path, "single"))
+    sp8, p8, step8 = load_snapshot(path8)
+    sp1, p1, step1 = load_snapshot(path1)
+    assert step8 == step1 == steps and sp8.particle_num == n
+    a, b = nb.as_floats(p8), nb.as_floats(p1)
+    assert np.isfinite(a).all()
+    # positions depend on the previous step's accelerations: the two runs add the same pair terms
+    # in different orders (different j splits), so fp32 rounding apart
+    scale = np.abs(b[:, 6:9]).max()
+    assert np.abs(a[:, 6:9] - b[:, 6:9]).max() <= 5e-6 * scale
+    assert np.abs(a[:, 0:3] - b[:, 0:3]).max() <= 2.5e-7                     # an ulp of a coordinate
+    # one more step from the one-device state, checked with the literal-fp32 oracle on three windows
+    for lo in (0, n // 2 - 64, n - 128):
+        ref = oracle.naive_step_f32(b, G, E, DT, lo, lo + 128)[lo:lo + 128]
+        multi = nb.OfflineHeadless(nb.NaiveSim, sp1, None, lambda _p: p1, device_ids=[0, 0, 0, 0])
+        multi.step()
+        got = nb.as_floats(multi.read_particles())[lo:lo + 128]
+        multi.destroy()
+        assert np.array_equal(bits(got[:, 0:3]), bits(ref[:, 0:3]))          # x' is bit-exact
+        assert np.abs(got[:, 6:9] - ref[:, 6:9]).max() <= 2e-5 * np.abs(ref[:, 6:9]).max()
+
+
+@pytest.mark.parametrize("n,world", [(1000, 3), (4096, 2), (300, 5), (8192, 8)])
+def test_multi_runner_matches_the_sharded_single_process_reference(gpu, oracle, n, world):
+    """nb_runner_create_multi from Python: ragged sizes (a last rank with few or no bodies), several
+    steps, against the fp64 oracle."""
+    nb = gpu
+    sp = nb.SimParams(particle_num=n)
+    init = nb.inits.spherical_init(sp, seed=40 + n)
+    r = nb.OfflineHeadless(nb.NaiveSim, sp, None, lambda _p: init, device_ids=[0] * world)
+    assert r.sim is None and r.sim_params().particle_num == n
+    r.step()
+    r.step_n(4)
+    assert r.step_num() == 5
+    got = nb.as_floats(r.read_particles())
+    r.destroy()
+    ref = oracle.naive_run_f64(nb.as_floats(init), G, E, DT, 5)
+    scale = np.abs(ref[:, 6:9]).max()
+    assert np.abs(got[:, 6:9] - ref[:, 6:9]).max() / scale < 2e-5
+    assert np.abs(got[:, 0:3] - ref[:, 0:3]).max() < 2e-6
+    assert np.array_equal(got[:, 9], nb.as_floats(init)[:, 9])
+
+
+def test_multi_runner_argument_errors(gpu):
+    nb = gpu
+    sp = nb.SimParams(particle_num=64)
+    with pytest.raises(nb.NBodyError):      # a device that does not exist
+        nb.OfflineHeadless(nb.NaiveSim, sp, None, lambda p: nb.inits.uniform_init(p), device_ids=[0, 99])
+    with pytest.raises(nb.NBodyError) as ei:  # Barnes-Hut on several GPUs is one process per GPU
+        nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(0.5), lambda p: nb.inits.uniform_init(p),
+                           device_ids=[0, 0])
+    assert ei.value.code == 5

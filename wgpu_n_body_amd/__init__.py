@@ -343,26 +343,39 @@ class OfflineHeadless:
     OfflineHeadless::<NaiveSim>::new(sim_params, add_params, init_fn)."""
 
     def __init__(self, sim_type, sim_params: SimParams, add_params: Optional[AddParams],
-                 init_fn: InitFn, device_id: int = -1):
+                 init_fn: InitFn, device_id: int = -1, device_ids: Optional[Sequence[int]] = None):
+        """device_ids: several GPUs of this process (nb_runner_create_multi; all-pairs only): rank r
+        owns a contiguous body range on device_ids[r]; a device id may repeat."""
         L = _lib.lib()
         if add_params is None or add_params.kind != sim_type.KIND:
             add_params = AddParams(sim_type.KIND, 0.0)
         sp, ap = sim_params.to_c(), add_params.to_c()
         cb, err = _init_trampoline(init_fn, sim_params)
         h = C.c_void_p()
-        rc = L.nb_runner_create(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
-                                int(device_id))
+        if device_ids is not None:
+            ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+            rc = L.nb_runner_create_multi(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
+                                          ids, len(device_ids))
+        else:
+            rc = L.nb_runner_create(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
+                                    int(device_id))
         if err:
             if rc == 0:
                 L.nb_runner_destroy(h)
             raise err[0]
         check(rc)
         self._h = h
-        self.sim = sim_type(L.nb_runner_sim(h), borrowed=True)
+        sim_h = L.nb_runner_sim(h)                 # NULL for a several-GPU runner
+        self.sim = sim_type(sim_h, borrowed=True) if sim_h else None
 
     @classmethod
-    def new(cls, sim_type, sim_params, add_params, init_fn, device_id: int = -1):
-        return cls(sim_type, sim_params, add_params, init_fn, device_id)
+    def new(cls, sim_type, sim_params, add_params, init_fn, device_id: int = -1, device_ids=None):
+        return cls(sim_type, sim_params, add_params, init_fn, device_id, device_ids)
+
+    def step_num(self) -> int:
+        v = C.c_uint64()
+        check(_lib.lib().nb_runner_step_num(self._h, C.byref(v)))
+        return int(v.value)
 
     def step(self) -> None:
         """offline_headless.rs:38-44: encode -> submit -> cleanup -> poll(Wait)."""
@@ -384,7 +397,8 @@ class OfflineHeadless:
 
     def destroy(self) -> None:
         if self._h:
-            self.sim._h = C.c_void_p()
+            if self.sim is not None:
+                self.sim._h = C.c_void_p()
             _lib.lib().nb_runner_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -24,10 +24,11 @@ SOURCES = [
     ("nb_naive.hip", []),
     ("nb_tree.hip", []),
     ("nb_abi.cpp", []),
+    ("nb_group.cpp", []),
     # the inits are specified bit-exactly (DESIGN.md "RNG"): no FMA contraction
     ("nb_inits.cpp", ["-ffp-contract=off"]),
 ]
-HEADERS = ["nb_common.hpp", "nb_sim.hpp", os.path.join(INCLUDE, "nbody.h")]
+HEADERS = ["nb_common.hpp", "nb_sim.hpp", "nb_group.hpp", os.path.join(INCLUDE, "nbody.h")]
 
 
 def _hipcc() -> str:

@@ -2,7 +2,10 @@
 // criterion groups in benches/benchmark.rs:12-49) over the drop-in API of simulator.hpp.
 //
 //   headless [--sim naive|tree] [--n N] [--steps S] [--theta T] [--init uniform|disc|spherical]
-//            [--seed K] [--device D] [--g G] [--dt DT] [--dump FILE]
+//            [--seed K] [--device D | --devices D0,D1,...] [--g G] [--dt DT] [--dump FILE]
+//
+// --devices: the all-pairs step sharded over several GPUs of this process (nb_runner_create_multi);
+// a device id may repeat.
 //
 // --dump FILE writes the final state as a snapshot (the layout of
 // wgpu_n_body_amd/snapshot.py: "NBSNAP01", u64 step, SimParams, Particle[n]).
@@ -10,6 +13,7 @@
 // Defaults reproduce headless.rs: TreeSim, 4,000,000 bodies, theta 0.75, uniform_init,
 // 10 steps, printing "Step Duration: {} us" per step.  (TreeSim needs the Barnes-Hut build;
 // pass --sim naive --n 65536 for the all-pairs path.)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,9 +35,10 @@ static bool write_snapshot(const std::string &path, const nbody::SimParams &sp,
 
 template <class Sim>
 static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbody::InitFn &init,
-               int steps, int device, const std::string &dump) {
+               int steps, int device, const std::vector<int> &devices, const std::string &dump) {
     std::puts("Initializing Simulation");
-    nbody::OfflineHeadless<Sim> runner(sp, ap, init, device);
+    nbody::OfflineHeadless<Sim> runner = devices.empty() ? nbody::OfflineHeadless<Sim>(sp, ap, init, device)
+                                                         : nbody::OfflineHeadless<Sim>(sp, ap, init, devices);
     std::puts("Running Simulation");
     for (int i = 0; i < steps; ++i) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -45,7 +50,7 @@ static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbo
     std::puts("Finished Running");
     if (!dump.empty()) {
         const std::vector<nbody::Particle> parts = runner.read_particles();
-        if (!write_snapshot(dump, sp, parts, runner.sim().step_num())) {
+        if (!write_snapshot(dump, sp, parts, runner.step_num())) {
             std::fprintf(stderr, "cannot write %s\n", dump.c_str());
             return 1;
         }
@@ -55,6 +60,7 @@ static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbo
 
 int main(int argc, char **argv) {
     std::string sim = "tree", init = "uniform", dump;
+    std::vector<int> devices;
     nbody::SimParams sp{4000000u, 0.000001f, 0.0001f, 0.016f};  // headless.rs:15-20
     float theta = 0.75f;
     int steps = 10, device = -1;
@@ -71,6 +77,13 @@ int main(int argc, char **argv) {
         else if (k == "--g") sp.g = (float)std::atof(v.c_str());
         else if (k == "--dt") sp.dt = (float)std::atof(v.c_str());
         else if (k == "--dump") dump = v;
+        else if (k == "--devices") {
+            for (size_t a = 0; a <= v.size();) {
+                const size_t b = std::min(v.find(',', a), v.size());
+                devices.push_back(std::atoi(v.substr(a, b - a).c_str()));
+                a = b + 1;
+            }
+        }
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     const nbody::InitFn fn = init == "disc" ? nbody::inits::disc_init(seed)
@@ -78,8 +91,8 @@ int main(int argc, char **argv) {
                                                  : nbody::inits::uniform_init(seed);
     try {
         if (sim == "naive")
-            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device, dump);
-        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device, dump);
+            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device, devices, dump);
+        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device, devices, dump);
     } catch (const nbody::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code(), e.what());
         return 1;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "nb_common.hpp"
+#include "nb_group.hpp"
 #include "nb_sim.hpp"
 
 namespace nb {
@@ -195,6 +196,15 @@ int NaiveSim::launch(int phase) {
     a.partial_stride = per_rank;
     a.partial_slices = partial_slices;
     a.phase = phase;
+    a.peers = peers[cur ^ 1];  // the finish kernel writes the new slice there too
+    if (a.peers.n && hi > lo && !(lo == 0 && hi == n)) {  // (a rank that owns no body, or all of them,
+                                                           // has nothing its peers wait for)
+        const NaivePlan p = plan_naive(n, lo, hi, variant, jsplit, phase != kPhaseAll);
+        if (phase == kPhaseAll && p.jsplit <= 1) {
+            set_error("a NaiveSim with peers steps in two phases (nb_sim_encode_phase)");
+            return NB_ERR_INVALID;
+        }
+    }
     NB_HIP_TRY(launch_naive_step(a, stream));
     return NB_OK;
 }
@@ -304,6 +314,19 @@ int NaiveSim::exchange_region(int index, void **dev_ptr, size_t *off, size_t *le
     return NB_OK;
 }
 
+int NaiveSim::set_peers(float4 *const *peer_buf0, float4 *const *peer_buf1, int count) {
+    if (count < 0 || count > kMaxPeers) {
+        set_error("at most %d peers", kMaxPeers);
+        return NB_ERR_INVALID;
+    }
+    for (int k = 0; k < count; ++k) {
+        peers[0].p[k] = peer_buf0[k];
+        peers[1].p[k] = peer_buf1[k];
+    }
+    peers[0].n = peers[1].n = (uint32_t)count;
+    return NB_OK;
+}
+
 int NaiveSim::set_tuning(const char *key, int value) {
     if (strcmp(key, "naive_variant") == 0) {
         if (value >= naive_variant_count()) {
@@ -325,13 +348,8 @@ int NaiveSim::set_tuning(const char *key, int value) {
     return NB_ERR_INVALID;
 }
 
-static int make_sim(nb_sim **out, const nb_sim_params *sp, const nb_add_params *ap,
-                    const nb_placement *pl, const nb_particle *particles, size_t count) {
-    if (!out || !sp) {
-        set_error("null argument");
-        return NB_ERR_INVALID;
-    }
-    *out = nullptr;
+int make_sim_impl(std::unique_ptr<SimBase> &out, const nb_sim_params *sp, const nb_add_params *ap,
+                  const nb_placement *pl, const nb_particle *particles, size_t count) {
     nb_add_params add{NB_NAIVE_SIM_PARAMS, 0.f};
     if (ap) add = *ap;
     std::unique_ptr<SimBase> impl;
@@ -358,6 +376,19 @@ static int make_sim(nb_sim **out, const nb_sim_params *sp, const nb_add_params *
     }
     if (int rc = impl->setup_common(*sp, add, pl)) return rc;
     if (int rc = impl->init(particles, count)) return rc;
+    out = std::move(impl);
+    return NB_OK;
+}
+
+static int make_sim(nb_sim **out, const nb_sim_params *sp, const nb_add_params *ap,
+                    const nb_placement *pl, const nb_particle *particles, size_t count) {
+    if (!out || !sp) {
+        set_error("null argument");
+        return NB_ERR_INVALID;
+    }
+    *out = nullptr;
+    std::unique_ptr<SimBase> impl;
+    if (int rc = make_sim_impl(impl, sp, ap, pl, particles, count)) return rc;
     nb_sim *s = new (std::nothrow) nb_sim();
     if (!s) {
         set_error("out of host memory");
@@ -552,7 +583,8 @@ int nb_sim_destroy(nb_sim *sim) {
 
 // ---- runner: OfflineHeadless<T>, src/runners/offline_headless.rs ---------------------------
 struct nb_runner {
-    nb_sim *sim = nullptr;
+    nb_sim *sim = nullptr;                  // one device
+    std::unique_ptr<NaiveGroup> group;      // several devices of this process (nb_runner_create_multi)
 };
 
 int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
@@ -576,22 +608,49 @@ int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
     })
 }
 
+int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
+                           nb_init_fn init, void *user, const int *device_ids, int n_devices) {
+    NB_GUARD({
+        if (!out || !sim_params || !init || !device_ids || n_devices < 1) {
+            set_error("nb_runner_create_multi: null argument or no device");
+            return NB_ERR_INVALID;
+        }
+        *out = nullptr;
+        if (n_devices == 1) return nb_runner_create(out, sim_params, add_params, init, user, device_ids[0]);
+        if (add_params && add_params->kind != NB_NAIVE_SIM_PARAMS) {
+            set_error("nb_runner_create_multi: the one-process runner shards the all-pairs simulator; several-GPU "
+                      "Barnes-Hut runs one process per GPU (nb_placement / the NB_PHASE_LET_* protocol)");
+            return NB_ERR_UNSUPPORTED;
+        }
+        std::vector<nb_particle> host(sim_params->particle_num);
+        init(sim_params, host.data(), user);  // init_fn(&sim_params) -> Vec<Particle>, once, on the host
+        std::unique_ptr<NaiveGroup> g;
+        if (int rc = NaiveGroup::create(g, *sim_params, host.data(), device_ids, n_devices)) return rc;
+        nb_runner *r = new nb_runner();
+        r->group = std::move(g);
+        *out = r;
+        return NB_OK;
+    })
+}
+
 // offline_headless.rs:38-44: encode -> submit -> cleanup -> poll(Wait)
 int nb_runner_step(nb_runner *runner) {
-    if (!runner || !runner->sim) {
+    if (!runner || (!runner->sim && !runner->group)) {
         set_error("null runner");
         return NB_ERR_INVALID;
     }
+    if (runner->group) NB_GUARD({ return runner->group->step_n(1); })
     if (int rc = nb_sim_encode(runner->sim)) return rc;
     if (int rc = nb_sim_cleanup(runner->sim)) return rc;
     return nb_sim_wait(runner->sim);
 }
 
 int nb_runner_step_n(nb_runner *runner, int n) {
-    if (!runner || !runner->sim) {
+    if (!runner || (!runner->sim && !runner->group)) {
         set_error("null runner");
         return NB_ERR_INVALID;
     }
+    if (runner->group) NB_GUARD({ return runner->group->step_n(n); })
     for (int k = 0; k < n; ++k) {
         if (int rc = nb_sim_encode(runner->sim)) return rc;
         if (int rc = nb_sim_cleanup(runner->sim)) return rc;
@@ -604,21 +663,45 @@ int nb_runner_read_particles(nb_runner *runner, nb_particle *dst, size_t n) {
         set_error("null runner");
         return NB_ERR_INVALID;
     }
+    if (runner->group) {
+        if (!dst && n) {
+            set_error("read_particles: dst is null");
+            return NB_ERR_INVALID;
+        }
+        NB_GUARD({ return runner->group->read_particles(dst, n); })
+    }
     return nb_sim_read_particles(runner->sim, dst, n);
 }
 
 int nb_runner_sim_params(const nb_runner *runner, nb_sim_params *out) {
-    if (!runner) {
+    if (!runner || !out) {
         set_error("null runner");
         return NB_ERR_INVALID;
     }
+    if (runner->group) {
+        *out = runner->group->params();
+        return NB_OK;
+    }
     return nb_sim_sim_params(runner->sim, out);
+}
+
+int nb_runner_step_num(const nb_runner *runner, uint64_t *out) {
+    if (!runner || !out) {
+        set_error("null runner");
+        return NB_ERR_INVALID;
+    }
+    if (runner->group) {
+        *out = runner->group->step_num();
+        return NB_OK;
+    }
+    return nb_sim_step_num(runner->sim, out);
 }
 
 nb_sim *nb_runner_sim(nb_runner *runner) { return runner ? runner->sim : nullptr; }
 
 int nb_runner_destroy(nb_runner *runner) {
     if (!runner) return NB_OK;
+    runner->group.reset();
     nb_sim_destroy(runner->sim);
     delete runner;
     return NB_OK;

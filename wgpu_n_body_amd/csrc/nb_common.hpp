@@ -35,6 +35,15 @@ constexpr uint32_t kITile = kWave * kIB;       // bodies per workgroup = 128
 constexpr uint32_t kJTile = 64;                // bodies per wave-load of the j stream
 constexpr uint32_t kPadTo = 256;               // posm buffers are padded to a multiple of this
 
+// Peer position buffers of a multi-GPU run inside one process (nb_group.cpp): the kernel that
+// finishes a rank's step stores the rank's new slice into every peer's next-step buffer as well
+// (direct stores over xGMI, one slice per point-to-point link) -- no copy, no collective.
+constexpr int kMaxPeers = 15;
+struct PeerDst {
+    float4 *p[kMaxPeers];
+    uint32_t n;
+};
+
 // ---- launchers implemented in nb_naive.hip ----------------------------------
 struct NaiveLaunch {
     const float4 *posm_src;  // [n_pad] x,y,z,m  (previous step, all bodies)
@@ -51,6 +60,7 @@ struct NaiveLaunch {
     uint32_t partial_stride; // bodies per slice (>= hi-lo)
     uint32_t partial_slices; // slices allocated
     int phase;               // kPhaseAll / kPhaseLocal / kPhaseRemote
+    PeerDst peers;           // where else the new slice goes (finish kernel only)
 };
 enum { kPhaseAll = 0, kPhaseLocal = 1, kPhaseRemote = 2 };
 // How a launch will be shaped for n total bodies of which this rank owns [lo, hi).

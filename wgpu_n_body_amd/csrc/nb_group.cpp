@@ -1,0 +1,282 @@
+// nb_group.cpp -- the all-pairs step on several GPUs of ONE process, behind the C ABI
+// (nb_runner_create_multi): no Python, no torch, no collective library in the step loop.
+//
+// There is no reference counterpart: the reference owns one adapter (src/runners/
+// offline_headless.rs:22-31).  What makes the path shard is in the shader itself: naive.wgsl's
+// update is Jacobi-style -- body i reads only the PREVIOUS step's positions of every body
+// (naive.wgsl:34) and writes only its own slot (naive.wgsl:68), and the two particle buffers
+// ping-pong (naive.rs:113-132).  So rank r of `world` owns the contiguous body range
+// [r per, (r+1) per), keeps a full copy of both position/mass buffers on its device, and the only
+// exchange of a step is every rank's new float4{x,y,z,m} slice reaching every peer.
+//
+// Here that exchange is not a copy and not a collective: the kernel that finishes a rank's step
+// (naive_finish_kernel) stores the new slice into its own next-step buffer AND, through peer
+// access, into the same slots of every peer's next-step buffer -- one slice per point-to-point
+// xGMI link, which is the shape of MI355X's fabric.  A step of rank r is then
+//     own j tiles  (needs only r's own slice, which r wrote itself)
+//     wait: event "step t-1 finished" of every peer   (their stores into r's buffer have landed)
+//     other j tiles + finish (stores to self and peers)
+//     record: event "step t finished" of r
+// One host thread per rank enqueues it on the rank's own stream; the threads meet at one
+// host barrier per step (an event must have been recorded before a peer enqueues its wait for
+// it).  The caller stays single-threaded: nb_runner_step returns when every rank has finished.
+//
+// The same device id may be given several times (ranks sharing a GPU): that is how the path is
+// tested on a one-GPU box, bit for bit the same code.
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nb_common.hpp"
+#include "nb_group.hpp"
+
+namespace nb {
+
+namespace {
+class HostBarrier {
+   public:
+    explicit HostBarrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const uint64_t gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            ++gen_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lk, [&] { return gen_ != gen; });
+        }
+    }
+
+   private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    uint64_t gen_ = 0;
+};
+}  // namespace
+
+struct NaiveGroup::Rank {
+    std::unique_ptr<SimBase> sim;
+    NaiveSim *naive = nullptr;
+    int device = 0;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    std::thread th;
+    int rc = NB_OK;
+    std::string err;
+};
+
+struct NaiveGroup::Shared {
+    std::mutex mu;
+    std::condition_variable cv_cmd, cv_done;
+    uint64_t cmd_seq = 0;  // bumped by the caller for every batch of steps
+    int cmd_steps = 0;
+    int finished = 0;
+    bool quit = false;
+    bool failed = false;   // some rank hit an error: the others stop working but keep meeting
+    std::unique_ptr<HostBarrier> bar;
+};
+
+NaiveGroup::NaiveGroup() : sh_(new Shared()) {}
+
+NaiveGroup::~NaiveGroup() {
+    {
+        std::lock_guard<std::mutex> lk(sh_->mu);
+        sh_->quit = true;
+    }
+    sh_->cv_cmd.notify_all();
+    for (auto &r : ranks_)
+        if (r->th.joinable()) r->th.join();
+    for (auto &r : ranks_) {
+        (void)hipSetDevice(r->device);
+        if (r->sim) (void)r->sim->wait();
+        for (hipEvent_t e : r->done)
+            if (e) (void)hipEventDestroy(e);
+        r->sim.reset();
+    }
+}
+
+int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_particle *particles,
+                       const int *device_ids, int n_devices) {
+    if (!device_ids || n_devices < 1 || n_devices > kMaxPeers + 1) {
+        set_error("nb_runner_create_multi: between 1 and %d devices", kMaxPeers + 1);
+        return NB_ERR_INVALID;
+    }
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        set_error("no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
+        return NB_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<NaiveGroup> g(new (std::nothrow) NaiveGroup());
+    if (!g) {
+        set_error("out of host memory");
+        return NB_ERR_ALLOC;
+    }
+    g->params_ = sp;
+    const int world = n_devices;
+    for (int r = 0; r < world; ++r) {
+        if (device_ids[r] < 0 || device_ids[r] >= visible) {
+            set_error("device_ids[%d] = %d out of range (%d devices)", r, device_ids[r], visible);
+            return NB_ERR_INVALID;
+        }
+        std::unique_ptr<Rank> rk(new Rank());
+        rk->device = device_ids[r];
+        nb_placement pl{};
+        pl.device_id = device_ids[r];
+        pl.rank = r;
+        pl.world = world;
+        const nb_add_params add{NB_NAIVE_SIM_PARAMS, 0.f};
+        if (int rc = make_sim_impl(rk->sim, &sp, &add, &pl, particles, sp.particle_num)) return rc;
+        rk->naive = static_cast<NaiveSim *>(rk->sim.get());
+        NB_HIP_TRY(hipSetDevice(rk->device));
+        for (hipEvent_t &e : rk->done) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g->ranks_.push_back(std::move(rk));
+    }
+    // peer access between every pair of distinct devices, then hand every rank its peers' buffers
+    for (int r = 0; r < world; ++r) {
+        NB_HIP_TRY(hipSetDevice(g->ranks_[r]->device));
+        for (int q = 0; q < world; ++q) {
+            const int a = g->ranks_[r]->device, b = g->ranks_[q]->device;
+            if (a == b) continue;
+            int can = 0;
+            NB_HIP_TRY(hipDeviceCanAccessPeer(&can, a, b));
+            if (!can) {
+                set_error("device %d cannot access device %d (no peer access): the one-process runner needs it", a, b);
+                return NB_ERR_UNSUPPORTED;
+            }
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) NB_HIP_TRY(e);
+            (void)hipGetLastError();
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        float4 *b0[kMaxPeers], *b1[kMaxPeers];
+        int k = 0;
+        for (int q = 0; q < world; ++q) {
+            if (q == r) continue;
+            float4 *bufs[2];
+            g->ranks_[q]->naive->position_buffers(bufs);
+            b0[k] = bufs[0];
+            b1[k] = bufs[1];
+            ++k;
+        }
+        if (int rc = g->ranks_[r]->naive->set_peers(b0, b1, k)) return rc;
+    }
+    g->sh_->bar.reset(new HostBarrier(world));
+    for (int r = 0; r < world; ++r) g->ranks_[r]->th = std::thread(&NaiveGroup::worker, g.get(), r);
+    out = std::move(g);
+    return NB_OK;
+}
+
+// One rank's host thread: waits for a batch of steps, enqueues them, waits for its stream.
+void NaiveGroup::worker(int r) {
+    Rank &me = *ranks_[r];
+    const int world = (int)ranks_.size();
+    (void)hipSetDevice(me.device);
+    uint64_t seen = 0;
+    for (;;) {
+        int steps = 0;
+        {
+            std::unique_lock<std::mutex> lk(sh_->mu);
+            sh_->cv_cmd.wait(lk, [&] { return sh_->quit || sh_->cmd_seq != seen; });
+            if (sh_->quit) return;
+            seen = sh_->cmd_seq;
+            steps = sh_->cmd_steps;
+        }
+        auto fail = [&](int rc) {
+            if (me.rc == NB_OK) {
+                me.rc = rc;
+                me.err = nb_last_error();
+            }
+            std::lock_guard<std::mutex> lk(sh_->mu);
+            sh_->failed = true;
+        };
+        auto failed = [&] {
+            std::lock_guard<std::mutex> lk(sh_->mu);
+            return sh_->failed;
+        };
+        for (int s = 0; s < steps; ++s) {
+            const uint64_t t = step_ + (uint64_t)s;  // absolute step index (same on every rank)
+            if (!failed())
+                if (int rc = me.sim->encode_phase(0)) fail(rc);  // own j tiles: nothing to wait for
+            sh_->bar->wait();  // every rank has recorded its "step t-1 finished"
+            if (!failed()) {
+                hipError_t e = hipSuccess;
+                if (t > 0)
+                    for (int q = 0; q < world && e == hipSuccess; ++q)
+                        if (q != r) e = hipStreamWaitEvent(me.sim->stream, ranks_[q]->done[(t - 1) & 1], 0);
+                if (e != hipSuccess) {
+                    set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+                    fail(NB_ERR_HIP);
+                } else if (int rc = me.sim->encode_phase(1)) {  // other tiles, finish: stores to self + peers
+                    fail(rc);
+                } else if ((e = hipEventRecord(me.done[t & 1], me.sim->stream)) != hipSuccess) {
+                    set_error("hipEventRecord failed: %s", hipGetErrorString(e));
+                    fail(NB_ERR_HIP);
+                }
+            }
+        }
+        if (int rc = me.sim->wait()) fail(rc);
+        sh_->bar->wait();  // every stream has drained: all slices have landed everywhere
+        {
+            std::lock_guard<std::mutex> lk(sh_->mu);
+            sh_->finished += 1;
+        }
+        sh_->cv_done.notify_all();
+    }
+}
+
+int NaiveGroup::step_n(int steps) {
+    if (steps <= 0) return NB_OK;
+    {
+        std::lock_guard<std::mutex> lk(sh_->mu);
+        if (sh_->failed) {
+            set_error("the runner is in a failed state: %s", first_error().c_str());
+            return NB_ERR_INVALID;
+        }
+        sh_->cmd_steps = steps;
+        sh_->finished = 0;
+        sh_->cmd_seq += 1;
+    }
+    sh_->cv_cmd.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(sh_->mu);
+        sh_->cv_done.wait(lk, [&] { return sh_->finished == (int)ranks_.size(); });
+    }
+    step_ += (uint64_t)steps;
+    for (auto &r : ranks_)
+        if (r->rc != NB_OK) {
+            set_error("rank on device %d: %s", r->device, r->err.c_str());
+            return r->rc;
+        }
+    return NB_OK;
+}
+
+std::string NaiveGroup::first_error() const {
+    for (auto &r : ranks_)
+        if (r->rc != NB_OK) return r->err;
+    return "";
+}
+
+// All positions/masses are everywhere; velocities and accelerations live with their owner.
+int NaiveGroup::read_particles(nb_particle *dst, size_t count) {
+    const size_t n = params_.particle_num;
+    if (count > n) {
+        set_error("read_particles: asked for %zu of %zu particles", count, n);
+        return NB_ERR_INVALID;
+    }
+    std::vector<nb_particle> tmp(n), all(n);
+    for (size_t r = 0; r < ranks_.size(); ++r) {
+        SimBase &s = *ranks_[r]->sim;
+        if (int rc = s.read_particles(tmp.data(), n)) return rc;
+        if (r == 0) all = tmp;
+        for (size_t i = s.lo; i < s.hi; ++i) all[i] = tmp[i];
+    }
+    for (size_t i = 0; i < count; ++i) dst[i] = all[i];
+    return NB_OK;
+}
+
+}  // namespace nb

@@ -1,0 +1,36 @@
+// nb_group.hpp -- the one-process multi-GPU all-pairs runner behind nb_runner_create_multi.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "nb_sim.hpp"
+
+namespace nb {
+
+class NaiveGroup {
+   public:
+    ~NaiveGroup();
+    // bodies [r per, (r+1) per) on device_ids[r]; a device id may repeat (ranks sharing a GPU)
+    static int create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_particle *particles,
+                      const int *device_ids, int n_devices);
+    int step_n(int steps);  // enqueue on every rank, return when every rank has finished
+    int read_particles(nb_particle *dst, size_t count);
+    const nb_sim_params &params() const { return params_; }
+    int world() const { return (int)ranks_.size(); }
+    uint64_t step_num() const { return step_; }
+
+   private:
+    NaiveGroup();
+    struct Rank;
+    struct Shared;
+    void worker(int r);
+    std::string first_error() const;
+    std::vector<std::unique_ptr<Rank>> ranks_;
+    std::unique_ptr<Shared> sh_;
+    nb_sim_params params_{};
+    uint64_t step_ = 0;
+};
+
+}  // namespace nb

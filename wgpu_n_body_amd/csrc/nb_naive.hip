@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * W) void naive_step_kernel(
 __global__ __launch_bounds__(256) void naive_finish_kernel(
     const float4 *__restrict__ posm_src, float4 *__restrict__ posm_dst, float4 *__restrict__ vel,
     float4 *__restrict__ acc, const float4 *__restrict__ partial, uint32_t partial_stride,
-    uint32_t js, uint32_t lo, uint32_t hi, float g, float dt) {
+    uint32_t js, uint32_t lo, uint32_t hi, float g, float dt, PeerDst peers) {
     const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
     const float4 p = posm_src[i], v = vel[i - lo], a = acc[i - lo];
@@ -295,7 +295,11 @@ __global__ __launch_bounds__(256) void naive_finish_kernel(
     }
     const float gdt = g * dt;
     const float fx = sx * gdt, fy = sy * gdt, fz = sz * gdt;
-    posm_dst[i] = float4{drift(p.x, vhx, dt), drift(p.y, vhy, dt), drift(p.z, vhz, dt), p.w};
+    const float4 pn = float4{drift(p.x, vhx, dt), drift(p.y, vhy, dt), drift(p.z, vhz, dt), p.w};
+    posm_dst[i] = pn;
+    // one-process multi-GPU: the same slot of every peer's next-step buffer (stores over xGMI;
+    // visible to the peer when this kernel has completed, which its stream waits for)
+    for (uint32_t k = 0; k < peers.n; ++k) peers.p[k][i] = pn;
     vel[i - lo] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.0f};
     acc[i - lo] = float4{fx, fy, fz, 0.0f};
 }
@@ -433,7 +437,7 @@ hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream) {
         if (p.jsplit > 1)
             hipLaunchKernelGGL(naive_finish_kernel, dim3((nl + 255u) / 256u), dim3(256), 0, stream,
                                a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride,
-                               p.jsplit, a.lo, a.hi, a.g, a.dt);
+                               p.jsplit, a.lo, a.hi, a.g, a.dt, a.peers);
         return hipGetLastError();
     }
     if (!p.two_phase || !a.partial || a.partial_slices < p.jsplit) return hipErrorInvalidValue;
@@ -449,7 +453,7 @@ hipError_t launch_naive_step(const NaiveLaunch &a, hipStream_t stream) {
                            a.partial_stride, a.n, a.n_pad, a.lo, a.hi, a.g, a.e, a.dt, rest);
         hipLaunchKernelGGL(naive_finish_kernel, dim3((nl + 255u) / 256u), dim3(256), 0, stream,
                            a.posm_src, a.posm_dst, a.vel, a.acc, a.partial, a.partial_stride, p.jsplit,
-                           a.lo, a.hi, a.g, a.dt);
+                           a.lo, a.hi, a.g, a.dt, a.peers);
     }
     return hipGetLastError();
 }

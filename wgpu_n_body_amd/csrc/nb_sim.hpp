@@ -78,8 +78,15 @@ class NaiveSim final : public SimBase {
     int exchange_count() override { return 1; }
     int exchange_region(int index, void **dev_ptr, size_t *off, size_t *len, size_t *total) override;
     int set_tuning(const char *key, int value) override;
+    // one-process multi-GPU (nb_group.cpp): this simulator's two position buffers, and the peers'
+    void position_buffers(float4 *out[2]) const {
+        out[0] = posm[0];
+        out[1] = posm[1];
+    }
+    int set_peers(float4 *const *peer_buf0, float4 *const *peer_buf1, int count);
 
    private:
+    PeerDst peers[2] = {};                 // peers[b]: the peers' buffers with ping-pong index b
     float4 *posm[2] = {nullptr, nullptr};  // ping-pong position/mass (naive.rs:99-132)
     bool own_posm = true;
     float4 *vel = nullptr, *acc = nullptr;  // this rank's bodies only
@@ -96,6 +103,10 @@ class NaiveSim final : public SimBase {
 
 // Implemented in nb_tree.hip; returns nullptr when the tree path is not built.
 SimBase *make_tree_sim();
+
+// nb_abi.cpp: construct a simulator object (what nb_sim_create does behind the handle)
+int make_sim_impl(std::unique_ptr<SimBase> &out, const nb_sim_params *sp, const nb_add_params *ap,
+                  const nb_placement *pl, const nb_particle *particles, size_t count);
 
 }  // namespace nb
 

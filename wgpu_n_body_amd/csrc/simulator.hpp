@@ -195,13 +195,32 @@ class OfflineHeadless {
         }
         check(rc);
     }
+    // several GPUs of this process (nb_runner_create_multi; all-pairs): rank r owns a contiguous
+    // body range on device_ids[r]
+    OfflineHeadless(const SimParams &sp, const AddParams &ap, const InitFn &init, const std::vector<int> &device_ids) {
+        detail::InitThunk thunk{&init, {}};
+        nb_add_params c = ap.c;
+        if (c.kind != T::kKind) c = nb_add_params{T::kKind, 0.f};
+        int rc = nb_runner_create_multi(&r_, &sp, &c, &detail::InitThunk::call, &thunk, device_ids.data(),
+                                        (int)device_ids.size());
+        if (!thunk.error.empty()) {
+            if (rc == NB_OK) nb_runner_destroy(r_);
+            throw Error(NB_ERR_INVALID, thunk.error);
+        }
+        check(rc);
+    }
     OfflineHeadless(const OfflineHeadless &) = delete;
     ~OfflineHeadless() {
         if (r_) nb_runner_destroy(r_);
     }
     void step() { check(nb_runner_step(r_)); }  // encode -> submit -> cleanup -> poll(Wait)
     void step_n(int n) { check(nb_runner_step_n(r_, n)); }
-    T sim() { return T(nb_runner_sim(r_)); }  // borrowed view of the runner's simulator
+    T sim() { return T(nb_runner_sim(r_)); }  // borrowed view of the runner's simulator (one device)
+    uint64_t step_num() const {
+        uint64_t v = 0;
+        check(nb_runner_step_num(r_, &v));
+        return v;
+    }
     std::vector<Particle> read_particles() {
         SimParams p{};
         check(nb_runner_sim_params(r_, &p));
