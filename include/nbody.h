@@ -210,6 +210,13 @@ int nb_sim_encode_phase(nb_sim *sim, int phase);
 #define NB_PHASE_LET_BUILD 3
 #define NB_PHASE_LET_WALK 4
 int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world);
+/* The same hand-over without a host round trip: the caller moves a FIXED number of records per peer
+ * -- `stride` records of rank r's segment `me` to record offset j * stride of region 3, j = r's
+ * position in rank order with `me` skipped -- sized from an earlier step's counts plus a margin, and
+ * calls this instead of nb_sim_let_set_imports.  The counts themselves stay on the device: region 1,
+ * all-gathered by the caller, is read by the kernel that prepares the imports.  A peer that has more
+ * than `stride` records for this rank is reported like a too small tree_let_cap (nb_sim_wait). */
+int nb_sim_let_set_import_stride(nb_sim *sim, uint32_t stride);
 
 /* Migration between LET steps.  A TreeSim created with more bodies than it starts with (the
  * surplus is headroom; tuning key "tree_let_active" = bodies in use) can hand over the bodies

@@ -20,3 +20,39 @@ def make_state(kind: str, n: int, seed: int, g: float = G) -> np.ndarray:
     fn = {"uniform": nb.inits.uniform_init, "disc": nb.inits.disc_init,
           "spherical": nb.inits.spherical_init}[kind]
     return nb.as_floats(fn(sp, seed=seed)).copy()
+
+
+def run_workers(cmds, port, tmp_path, timeout=300):
+    """Start one worker process per rank (output to files, not pipes); on a time-out or a failure
+    kill every sibling before reporting, so that no orphan keeps the GPU."""
+    import subprocess
+    world = len(cmds)
+    procs, logs = [], []
+    for rank, cmd in enumerate(cmds):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        log = open(os.path.join(tmp_path, f"worker{rank}.log"), "w")
+        logs.append(log)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT))
+    failed = None
+    try:
+        for rank, p in enumerate(procs):
+            try:
+                if p.wait(timeout=timeout) != 0 and failed is None:
+                    failed = rank
+            except subprocess.TimeoutExpired:
+                failed = rank if failed is None else failed
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+        for log in logs:
+            log.close()
+    if failed is not None:
+        tails = "\n".join(f"--- rank {r} ---\n" + open(os.path.join(tmp_path, f"worker{r}.log")).read()[-3000:]
+                          for r in range(world))
+        raise AssertionError(f"worker {failed} failed or timed out\n{tails}")
+
+

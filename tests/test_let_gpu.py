@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import ROOT, bits
+from tests.helpers import ROOT, bits, run_workers
 
 pytestmark = pytest.mark.gpu
 
@@ -54,8 +54,9 @@ class LetGroup:
     """`world` TreeSims on one GPU running the LET protocol, exchanges by hipMemcpy."""
 
     def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0,
-                 own_first=False):
+                 own_first=False, fixed_stride=None):
         self.nb, self.world, self.hip = nb, world, _hip()
+        self.fixed_stride = fixed_stride   # records per peer moved blindly; counts stay on the device
         self.migrate_every, self.steps_done, self.own_first = migrate_every, 0, own_first
         self.sp, self.theta, self.prune, self.cap = sp, theta, prune, cap
         self.sims = []
@@ -151,11 +152,26 @@ class LetGroup:
             s.encode_phase(BUILD)
             if self.own_first:
                 s.encode_phase(WALK_OWN)      # while the exchange below is "in flight"
-        counts = self._matrix(1)
-        self.counts = counts
-        received = self._all_to_all(counts, 2, 3, REC)
-        for me, s in enumerate(self.sims):
-            s.let_set_imports(received[me])
+        if self.fixed_stride:
+            # nb_sim_let_set_import_stride: all-gather the counts (device to device, never read on
+            # the host), move a fixed number of records per peer
+            self._all_gather(1)
+            F = self.fixed_stride
+            for me, s in enumerate(self.sims):
+                rptr = s.exchange_region(3)[0]
+                for r in range(self.world):
+                    if r == me:
+                        continue
+                    j = r if r < me else r - 1
+                    sptr, _o, seg, _t = self.sims[r].exchange_region(2)
+                    self._copy(rptr + j * F * REC, sptr + me * seg, F * REC)
+                s.let_set_import_stride(F)
+        else:
+            counts = self._matrix(1)
+            self.counts = counts
+            received = self._all_to_all(counts, 2, 3, REC)
+            for me, s in enumerate(self.sims):
+                s.let_set_imports(received[me])
         for s in self.sims:
             s.encode_phase(WALK)
         self.steps_done += 1
@@ -203,6 +219,37 @@ def test_let_pruning_changes_no_bit(gpu, n, world, theta, init):
     assert pruned.counts[off].sum() < (0.8 if init == "disc" else 0.7) * whole.counts[off].sum()
     pruned.destroy()
     whole.destroy()
+
+
+@pytest.mark.parametrize("n,world,own_first", [(6000, 2, False), (9000, 3, True), (20000, 4, False), (3000, 1, False)])
+def test_let_fixed_stride_imports_change_no_bit(gpu, n, world, own_first):
+    """The hand-over without a host round trip (nb_sim_let_set_import_stride: a fixed number of
+    records per peer, the real counts read on the device) walks the same trees in the same order
+    as the packed hand-over (nb_sim_let_set_imports): identical bodies; too small a stride is
+    reported, not walked."""
+    nb = gpu
+    sp, p = tagged(nb, n, 27)
+    packed = LetGroup(nb, sp, p, world, 0.5, own_first=own_first, migrate_every=2)
+    packed.step()
+    need = int(packed.counts.max()) if world > 1 else 1
+    fixed = LetGroup(nb, sp, p, world, 0.5, own_first=own_first, migrate_every=2, fixed_stride=need + need // 4 + 64)
+    fixed.step()
+    for _ in range(3):
+        packed.step()
+        fixed.step()
+    a, b = by_tag(nb, packed.particles()), by_tag(nb, fixed.particles())
+    assert np.isfinite(a).all()
+    assert np.array_equal(bits(a), bits(b))
+    packed.destroy()
+    fixed.destroy()
+    if world > 1:
+        small = LetGroup(nb, sp, p, world, 0.5, fixed_stride=max(8, need // 4))
+        with pytest.raises(nb.NBodyError) as ex:
+            small.step()
+            for s in small.sims:
+                s.wait()
+        assert "tree_let_cap" in str(ex.value) or "records" in str(ex.value)
+        small.destroy()
 
 
 def test_let_with_theta_to_zero_is_all_pairs(gpu, oracle):
@@ -370,7 +417,8 @@ def test_let_migration_keeps_the_waves_coherent(gpu):
     assert longest[1, 1] < 0.8 * longest[1, 0], longest
 
 
-@pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap"), (3, "let-rebalance")])
+@pytest.mark.parametrize("world,mode", [(2, "let"), (3, "let"), (2, "let-overlap"), (3, "let-rebalance"),
+                                        (3, "let-async")])
 def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     """The product class (LetTreeSim: torch.distributed for the three exchanges) as `world`
     processes on this one GPU, gloo standing in for RCCL == the in-process emulation above."""
@@ -378,22 +426,22 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     import subprocess
     import sys
     nb = gpu
-    n, steps, theta = 6000, 3, 0.5
+    n, steps, theta = 6000, (9 if mode == "let-async" else 3), 0.5
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
-             str(n), str(steps), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o
+    run_workers([[sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path), str(n),
+                  str(steps), mode]] * world, port, tmp_path)
     sp, p0 = tagged(nb, n, 27)
-    grp = LetGroup(nb, sp, p0, world, theta, migrate_every=1)   # LetTreeSim's default schedule
+    if mode == "let-async":
+        # steps 0 and 1 learn the counts synchronously; from then on only the steps that migrate
+        # (every 4th) read anything of the current step on the host
+        for r in range(world):
+            syncs = np.load(os.path.join(tmp_path, f"syncs{r}.npy"))
+            assert syncs[0] >= 1 and syncs[1] >= 1
+            for k in range(2, steps):
+                assert (syncs[k] == 0) == (k % 4 != 0), (r, k, syncs)
+    grp = LetGroup(nb, sp, p0, world, theta, migrate_every=(4 if mode == "let-async" else 1))
     for k in range(steps):
         if mode == "let-rebalance" and k == 2:
             grp.rebalance()
@@ -403,6 +451,26 @@ def test_let_tree_sim_processes_share_one_gpu(gpu, tmp_path, world, mode):
     got = np.concatenate([np.load(os.path.join(tmp_path, f"rank{r}.npy")) for r in range(world)])
     got = got[np.argsort(got[:, 9], kind="stable")]
     assert np.array_equal(bits(got), bits(want))
+
+
+def test_rccl_code_paths_on_one_rank(gpu, tmp_path):
+    """RCCL refuses several ranks on one device, so on this one-GPU box the product's RCCL branches
+    run as a 1-rank NCCL group with the collectives forced: all_gather_into_tensor on views of
+    library memory (all-pairs, replicated tree, LET regions), dist.all_to_all on zero-length device
+    views, and the LET step without host reads.  Every sharded class == its single simulator."""
+    import json
+    import socket
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    run_workers([[sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path), "5000", "3",
+                  "rccl-world1"]], port, tmp_path)
+    rep = json.load(open(os.path.join(tmp_path, "rccl_world1.json")))
+    assert rep["naive"] and rep["tree"] and rep["let"], rep
+    assert rep["let_async_used"]
+    # the first two steps and the migrating ones read counts on the host; the others do not
+    assert rep["let_syncs_per_step"][3] == 0 and rep["let_syncs_per_step"][5] == 0, rep
 
 
 def test_energy_and_momentum_after_many_steps_track_all_pairs(gpu, oracle):

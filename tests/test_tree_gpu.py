@@ -282,16 +282,9 @@ def test_sharded_tree_sim_ranks_on_one_gpu(gpu, tmp_path, n, world, mode):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path),
-             str(n), str(steps), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        out, _ = p.communicate(timeout=300)
-        assert p.returncode == 0, out.decode(errors="replace")[-3000:]
+    from tests.helpers import run_workers
+    run_workers([[sys.executable, os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(tmp_path), str(n),
+                  str(steps), mode]] * world, port, tmp_path)
     sp = nb.SimParams(particle_num=n)
     single = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5),
                                        nb.inits.uniform_init(sp, seed=77))

@@ -232,6 +232,11 @@ class Simulator:
         arr = (C.c_uint32 * len(counts))(*[int(c) for c in counts])
         check(_lib.lib().nb_sim_let_set_imports(self._h, arr, len(counts)))
 
+    def let_set_import_stride(self, stride: int) -> None:
+        """LET protocol without a host round trip (nb_sim_let_set_import_stride): this step's imports
+        are fixed-stride segments, their counts are read on the device."""
+        check(_lib.lib().nb_sim_let_set_import_stride(self._h, int(stride)))
+
     def let_set_owners(self, splits, ref_bound: float, seg_cap: int) -> None:
         """LET migration (nb_sim_let_set_owners): rank r owns reference keys [splits[r-1], splits[r])."""
         world = len(splits) + 1

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "nb_init_uniform", "nb_init_disc", "nb_init_spherical",
     "nb_shard_bodies_per_rank", "nb_shard_padded_bodies",
     "nb_sim_create", "nb_sim_create_from_particles", "nb_sim_encode", "nb_sim_encode_phase",
-    "nb_sim_let_set_imports", "nb_sim_let_set_owners", "nb_sim_let_set_arrivals", "nb_sim_cleanup",
+    "nb_sim_let_set_imports", "nb_sim_let_set_import_stride", "nb_sim_let_set_owners", "nb_sim_let_set_arrivals", "nb_sim_cleanup",
     "nb_sim_wait", "nb_sim_sim_params", "nb_sim_read_particles", "nb_sim_write_particles",
     "nb_sim_read_tree", "nb_sim_exchange_region", "nb_sim_exchange_count",
     "nb_sim_exchange_region_i", "nb_sim_step_num", "nb_sim_encode_n_timed",
@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
         getattr(L, name).argtypes = [vp]
     L.nb_sim_encode_phase.argtypes = [vp, C.c_int]
     L.nb_sim_let_set_imports.argtypes = [vp, P(C.c_uint32), C.c_int]
+    L.nb_sim_let_set_import_stride.argtypes = [vp, C.c_uint32]
     L.nb_sim_let_set_owners.argtypes = [vp, P(C.c_ulonglong), C.c_int, C.c_float, C.c_uint32]
     L.nb_sim_let_set_arrivals.argtypes = [vp, C.c_uint32, P(C.c_uint32), C.c_int]
     L.nb_sim_sim_params.argtypes = [vp, P(nb_sim_params)]

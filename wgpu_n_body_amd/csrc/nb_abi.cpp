@@ -484,6 +484,9 @@ int nb_sim_encode_phase(nb_sim *sim, int phase) { NB_SIM_CALL(sim, encode_phase(
 int nb_sim_let_set_imports(nb_sim *sim, const uint32_t *counts, int world) {
     NB_SIM_CALL(sim, let_set_imports(counts, world))
 }
+int nb_sim_let_set_import_stride(nb_sim *sim, uint32_t stride) {
+    NB_SIM_CALL(sim, let_set_import_stride(stride))
+}
 int nb_sim_let_set_owners(nb_sim *sim, const unsigned long long *splits, int world, float ref_bound,
                           uint32_t seg_cap) {
     NB_SIM_CALL(sim, let_set_owners(splits, world, ref_bound, seg_cap))

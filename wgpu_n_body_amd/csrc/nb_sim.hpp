@@ -36,6 +36,10 @@ class SimBase {
         set_error("let_set_imports: not a TreeSim");
         return NB_ERR_UNSUPPORTED;
     }
+    virtual int let_set_import_stride(uint32_t) {
+        set_error("let_set_import_stride: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int let_set_owners(const unsigned long long *, int, float, uint32_t) {
         set_error("let_set_owners: not a TreeSim");
         return NB_ERR_UNSUPPORTED;

@@ -778,11 +778,12 @@ template <bool COUNT, int PART = 0>
 __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
-    WalkRoots roots,
+    WalkRoots roots_arg,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ bound_slots) {
+    uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
+    const WalkRoots roots = roots_dev ? *roots_dev : roots_arg;  // (device-made roots: fixed-stride LET imports)
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1012,11 +1013,12 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
 template <int G, bool COUNT, int PART>
 __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_cells_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
-    const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots, uint32_t split,
+    const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots_arg, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ bound_slots) {
+    uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
+    const WalkRoots roots = roots_dev ? *roots_dev : roots_arg;  // (device-made roots: fixed-stride LET imports)
     __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1504,6 +1506,44 @@ __global__ void let_rebase_kernel(NodeRec *__restrict__ imp, LetSegments segs, u
     imp[i] = r;
 }
 
+// The same for imports that arrive in FIXED-STRIDE segments (nb_sim_let_set_import_stride): segment j
+// (the j-th peer in rank order, this rank skipped) starts at record j * stride, and how many of its
+// records are real is read HERE, on the device, from the all-gathered counts matrix -- the host
+// never sees the counts, so a step needs no host synchronisation.  Also writes the walk's roots.
+__global__ void let_rebase_fixed_kernel(NodeRec *__restrict__ imp, const uint32_t *__restrict__ counts_all,
+                                        uint32_t me, uint32_t world, uint32_t stride, uint32_t import_base,
+                                        uint32_t own_root, WalkRoots *__restrict__ roots_dev,
+                                        uint32_t *__restrict__ status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0u) {  // the trees this rank walks: its own (optional), then the non-empty imports in rank order
+        WalkRoots rt{};
+        if (own_root) rt.id[rt.count++] = 0u;
+        for (uint32_t r = 0; r < world; ++r) {
+            if (r == me) continue;
+            const uint32_t c = counts_all[r * world + me], j = r < me ? r : r - 1u;
+            if (c > stride) atomicAdd(&status[0], 1u);  // the sender had more than the segment holds
+            if (c) rt.id[rt.count++] = import_base + j * stride;
+        }
+        *roots_dev = rt;
+    }
+    if (world < 2u || i >= (world - 1u) * stride) return;
+    const uint32_t j = i / stride, local = i - j * stride, r = j < me ? j : j + 1u;
+    const uint32_t seg_n = min(counts_all[r * world + me], stride);
+    if (local >= seg_n) return;
+    NodeRec rc = imp[i];
+    rc.self_pos = ~0u;
+    if (rc.count != 0u) {
+        if (rc.count <= 8u && rc.first > local && rc.first + rc.count <= seg_n) {
+            rc.first += import_base + j * stride;
+        } else {
+            rc.first = 0u;
+            rc.count = 0u;
+            rc.ssize2 = -1.0f;
+        }
+    }
+    imp[i] = rc;
+}
+
 // ---- AoS conversion of the device tree (nb_sim_read_tree) ---------------------------------------
 __global__ void tree_to_aos_kernel(const float4 *__restrict__ cogm, const uint32_t *__restrict__ bodies,
                                    const uint32_t *__restrict__ child, uint32_t n_nodes,
@@ -1763,6 +1803,17 @@ class TreeSim final : public SimBase {
             return NB_ERR_INVALID;
         }
         WalkRoots roots{};
+        if (let_import_stride) {
+            // imports in fixed-stride segments, their counts read on the device (no host round trip)
+            const uint32_t total = (uint32_t)(let_world - 1) * let_import_stride;
+            hipLaunchKernelGGL(let_rebase_fixed_kernel, dim3(std::max(1u, (total + 255u) / 256u)), b256, 0, stream,
+                               rec + node_cap, let_counts, (uint32_t)let_rank, (uint32_t)let_world,
+                               let_import_stride, node_cap, (n && !let_own_walked) ? 1u : 0u, let_roots_dev, status);
+            if (n) {
+                if (int rc = enqueue_walk(roots, let_own_walked ? 2 : 0, let_own_walked ? 0u : 1u, let_roots_dev))
+                    return rc;
+            }
+        } else {
         if (n && !let_own_walked) roots.id[roots.count++] = 0u;
         const uint32_t total = let_segs.off[let_segs.world];
         if (total) {
@@ -1774,6 +1825,7 @@ class TreeSim final : public SimBase {
         if (n) {
             // set 0 = the own tree (already walked by NB_PHASE_LET_WALK_OWN if let_own_walked), set 1 = the imports
             if (int rc = enqueue_walk(roots, let_own_walked ? 2 : 0, let_own_walked ? 0u : 1u)) return rc;
+        }
         }
         let_own_walked = false;
         step_num += 1;
@@ -1879,6 +1931,19 @@ class TreeSim final : public SimBase {
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
     }
 
+    // Imports of this step arrive in region 3 as (world - 1) segments of `stride` records, in rank
+    // order with this rank skipped; how many records of a segment are real is taken on the device
+    // from the all-gathered counts (region 1).  Replaces nb_sim_let_set_imports for this step.
+    int let_set_import_stride(uint32_t stride) override {
+        if (!let_world || !let_send || stride == 0 || stride > let_cap) {
+            set_error("let_set_import_stride: needs the LET buffers and 0 < stride <= tree_let_cap (%u)", let_cap);
+            return NB_ERR_INVALID;
+        }
+        let_import_stride = stride;
+        let_imports_set = true;
+        return NB_OK;
+    }
+
     int let_set_imports(const uint32_t *counts, int world) override {
         if (!let_world || world != let_world || !counts) {
             set_error("let_set_imports: world %d does not match tree_let_world %d", world, let_world);
@@ -1895,6 +1960,7 @@ class TreeSim final : public SimBase {
             }
         }
         let_segs.off[world] = (uint32_t)run;
+        let_import_stride = 0;
         let_imports_set = true;
         return NB_OK;
     }
@@ -1918,6 +1984,7 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&let_meta, sizeof(uint32_t) * kLetMetaWords * w)) return rc;
         if (int rc = alloc(&let_counts, sizeof(uint32_t) * w * w)) return rc;
         if (int rc = alloc(&let_out_slot, sizeof(uint32_t) * w * (size_t)node_cap)) return rc;
+        if (int rc = alloc(&let_roots_dev, sizeof(WalkRoots))) return rc;
         if (int rc = alloc(&let_send, sizeof(NodeRec) * w * (size_t)cap)) return rc;
         // the walk addresses own and imported records through one table: own tree first, imports after
         NodeRec *table = nullptr;
@@ -2008,7 +2075,8 @@ class TreeSim final : public SimBase {
     }
 
     // part: 0 whole step, 1 own-tree sums only, 2 continue from those sums and integrate
-    int enqueue_walk(const WalkRoots &roots, int part = 0, uint32_t split = 1) {
+    int enqueue_walk(const WalkRoots &roots, int part = 0, uint32_t split = 1,
+                     const WalkRoots *roots_dev = nullptr) {
         const int s = cur, d = cur ^ 1;
         uint32_t *status = scalars + 4;
         const dim3 b256(256);
@@ -2033,7 +2101,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(COUNT, PART)                                                                              \
     hipLaunchKernelGGL((walk_kernel<COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,  \
                        roots, posm[s], vel[s], acc[s], lo, hi, shift, params.g, params.e, params.dt,      \
-                       theta, status, counters, bslots)
+                       theta, status, counters, bslots, roots_dev)
             if (count_visits) {
                 if (part == 0) NB_WALK(true, 0); else if (part == 1) NB_WALK(true, 1); else NB_WALK(true, 2);
             } else {
@@ -2048,7 +2116,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(G, COUNT, PART)                                                                               \
     hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, bwalk, 0, stream, posm[d], vel[d], acc[d],  \
                        rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt,     \
-                       theta, status, counters, bslots)
+                       theta, status, counters, bslots, roots_dev)
 #define NB_WALK_P(G, COUNT)                                                                   \
     do {                                                                                      \
         if (part == 0) NB_WALK(G, COUNT, 0); else if (part == 1) NB_WALK(G, COUNT, 1); else NB_WALK(G, COUNT, 2); \
@@ -2373,6 +2441,8 @@ class TreeSim final : public SimBase {
     uint32_t *let_meta = nullptr, *let_counts = nullptr, *let_out_slot = nullptr;
     NodeRec *let_send = nullptr;
     LetSegments let_segs{};
+    uint32_t let_import_stride = 0;       // != 0: this step's imports are fixed-stride segments
+    WalkRoots *let_roots_dev = nullptr;
     bool let_imports_set = false, let_prune = true, let_arrivals_pending = false, let_own_walked = false;
     uint32_t n_capacity = 0, let_mig_cap = 0;
     uint32_t *let_mig_counts = nullptr;

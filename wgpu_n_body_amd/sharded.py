@@ -343,14 +343,15 @@ def morton_domains(particles: np.ndarray, world: int, slack: float = 0.02, with_
 
 
 def exchange_segments(send, seg: int, recv, counts: np.ndarray, me: int, world: int, R: int, group=None,
-                      sync=None) -> list:
+                      sync=None, force: bool = False) -> list:
     """The all-to-all-v of the LET protocol.  `send` holds `world` segments of `seg` elements;
     counts[r][q] records of R elements each go from rank r to rank q.  Moves counts[r][me]
     records of every rank r's segment `me` into `recv`, packed in rank order (nothing for
     r == me), and returns the per-rank record counts received.
     RCCL: one grouped all-to-all on device views.  Other backends (gloo: the CPU tests and the
     one-GPU rehearsal): point-to-point through host memory (`sync` first, if the data is the
-    product of enqueued device work)."""
+    product of enqueued device work).  force: issue the collective even at world == 1 (zero-length
+    views; how the RCCL branch is exercised on a one-GPU box)."""
     import torch
     import torch.distributed as dist
     recv_counts = [0 if r == me else int(counts[r, me]) for r in range(world)]
@@ -358,7 +359,7 @@ def exchange_segments(send, seg: int, recv, counts: np.ndarray, me: int, world: 
     offs = np.concatenate([[0], np.cumsum(recv_counts)])
     outs = [recv[int(offs[r]) * R:(int(offs[r]) + recv_counts[r]) * R] for r in range(world)]
     ins = [send[q * seg:q * seg + send_counts[q] * R] for q in range(world)]
-    if world == 1:
+    if world == 1 and not force:
         return recv_counts
     if dist.get_backend(group) == "nccl":
         dist.all_to_all(outs, ins, group=group)
@@ -409,10 +410,12 @@ class LetTreeSim:
 
     META, BUILD, WALK, MIGRATE, WALK_OWN = 2, 3, 4, 5, 6
     HEADROOM = 1.25     # body capacity of a rank relative to its start-up share
+    STRIDE_MARGIN = 1.5  # fixed-stride exchange: records per peer = margin x the largest count seen + 1024
+    force_exchange = False   # issue the collectives even at world == 1 (one-GPU rehearsal of the RCCL path)
 
     def __init__(self, sim_params: SimParams, theta: float, particles, rank: int, world: int,
                  device_index: int, group=None, let_cap: Optional[int] = None, migrate_every: int = 1,
-                 overlap: bool = False):
+                 overlap: bool = False, async_exchange: Optional[bool] = None):
         import torch
         self._torch = torch
         self.rank, self.world, self.group = rank, world, group
@@ -434,6 +437,15 @@ class LetTreeSim:
         # one GPU, the only rehearsal available here, run slower with it).
         self.overlap = bool(overlap)
         self.side = torch.cuda.Stream(self._dev, priority=-1)   # its small kernels must not queue behind the walk
+        # async_exchange: steps between migrations issue NO host synchronisation -- the export counts
+        # are all-gathered and consumed on the device (nb_sim_let_set_import_stride) and a fixed
+        # number of records per peer is moved, sized from the counts of two steps ago (read back
+        # asynchronously) plus a margin.  Default: on under RCCL, off under gloo (whose exchange
+        # goes through host memory anyway).
+        self.async_exchange = async_exchange
+        self.host_syncs = 0          # blocking host reads of the CURRENT step's data issued by encode()
+        self._readbacks = {}         # step -> (pinned counts tensor, event)
+        self._known_counts = {}      # step -> counts matrix (numpy), from a synchronous step or a read-back
         self._adopt(as_particles(particles))
 
     # -- domain set-up -------------------------------------------------------------------------
@@ -468,19 +480,57 @@ class LetTreeSim:
     def _all_gather(self, k: int) -> None:
         import torch.distributed as dist
         full, off, ln = self._views[k]
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             dist.all_gather_into_tensor(full, full[off:off + ln], group=self.group)
 
     def _exchange_segments(self, counts: np.ndarray, k_send: int, k_recv: int, R: int) -> list:
         send, _, seg = self._views[k_send]
         recv, _, _ = self._views[k_recv]
         return exchange_segments(send, seg, recv, counts, self.rank, self.world, R, self.group,
-                                 sync=lambda: self._torch.cuda.current_stream(self._dev).synchronize())
+                                 sync=lambda: self._torch.cuda.current_stream(self._dev).synchronize(),
+                                 force=self.force_exchange)
 
     def _counts_matrix(self, k: int) -> np.ndarray:
         t = self._torch
         self._all_gather(k)
+        self.host_syncs += 1          # a blocking read of this step's counts
         return self._views[k][0].view(t.int32).cpu().numpy().astype(np.int64).reshape(self.world, self.world)
+
+    def _use_async(self) -> bool:
+        if self.async_exchange is not None:
+            return bool(self.async_exchange)
+        import torch.distributed as dist
+        return (self.world > 1 or self.force_exchange) and dist.is_initialized() and \
+            dist.get_backend(self.group) == "nccl"
+
+    def _planned_stride(self):
+        """Records per peer for this step's fixed-stride exchange, or None when the counts of two
+        steps ago are not known yet (the first steps, or right after a migration).  Every rank
+        derives it from the same all-gathered matrix of the same step, so all ranks agree."""
+        k = self.step_num - 2
+        if k in self._readbacks:                     # complete by now unless the host runs > 2 steps ahead
+            pinned, ev = self._readbacks.pop(k)
+            ev.synchronize()
+            self._known_counts[k] = pinned.numpy().astype(np.int64).reshape(self.world, self.world).copy()
+        for old in [j for j in self._known_counts if j < k]:
+            del self._known_counts[old]
+        c = self._known_counts.get(k)
+        if c is None:
+            return None
+        off = c - np.diag(np.diag(c))
+        need = int(off.max(initial=0))
+        stride = int(need * self.STRIDE_MARGIN) + 1024
+        return min((stride + 63) // 64 * 64, self.cap)
+
+    def _queue_counts_readback(self) -> None:
+        """Copy this step's all-gathered counts matrix to pinned host memory without waiting."""
+        t = self._torch
+        src = self._views[1][0].view(t.int32)
+        pinned = t.empty(src.shape, dtype=t.int32, pin_memory=True)
+        pinned.copy_(src, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self._dev))
+        self._readbacks[self.step_num] = (pinned, ev)
 
     def migrate(self) -> None:
         """Hand the bodies that left this rank's key range to their new owners (collective)."""
@@ -495,6 +545,7 @@ class LetTreeSim:
             self.sim.let_set_arrivals(int(counts[self.rank, self.rank]), recv)
         self.counts = [int(counts[:, r].sum()) for r in range(self.world)]
         self.last_migration = counts
+        self.host_syncs += 1
 
     def encode(self) -> None:
         t = self._torch
@@ -519,6 +570,20 @@ class LetTreeSim:
                     arrived.record(self.side)
                 self.stream.wait_event(arrived)
             else:
+                stride = self._planned_stride() if self._use_async() else None
+                if stride is not None:
+                    # no host round trip: counts all-gathered and consumed on the device, a fixed
+                    # number of records per peer on the wire
+                    self._all_gather(1)
+                    fixed = np.full((self.world, self.world), stride, dtype=np.int64)
+                    np.fill_diagonal(fixed, 0)
+                    self._exchange_segments(fixed, 2, 3, 8)
+                    self._queue_counts_readback()
+                    self.sim.let_set_import_stride(stride)
+                    self.sim.encode_phase(self.WALK)
+                    self.last_stride = stride
+                    self.step_num += 1
+                    return
                 _t0 = _now()
                 counts = self._counts_matrix(1)
                 _t1 = _now()
@@ -528,6 +593,7 @@ class LetTreeSim:
                 print(f"[let rank {self.rank} step {self.step_num}] counts {(_t1 - _t0) * 1e3:.2f} ms, "
                       f"exchange {(_t2 - _t1) * 1e3:.2f} ms", flush=True)
             self.last_counts = counts
+            self._known_counts[self.step_num] = counts
             self.sim.let_set_imports(recv_counts)
             self.sim.encode_phase(self.WALK)
         self.step_num += 1
@@ -551,9 +617,22 @@ class LetTreeSim:
         mine = self.read_local()
         if self.world == 1:
             return mine
-        out = [None] * self.world
-        dist.all_gather_object(out, mine.tobytes(), group=self.group)
-        return np.concatenate([np.frombuffer(b, dtype=mine.dtype) for b in out])
+        # tensor collectives (no pickling): the body counts, then the 40-byte rows padded to the
+        # largest count -- on the device under RCCL, on the host under gloo
+        t = self._torch
+        dev = self._dev if dist.get_backend(self.group) == "nccl" else t.device("cpu")
+        nloc = t.tensor([len(mine)], dtype=t.int64, device=dev)
+        counts = t.zeros(self.world, dtype=t.int64, device=dev)
+        dist.all_gather_into_tensor(counts, nloc, group=self.group)
+        counts = [int(c) for c in counts.cpu()]
+        width = max(counts) * 10
+        row = t.zeros(width, dtype=t.float32, device=dev)
+        row[:len(mine) * 10] = t.from_numpy(as_floats(mine).reshape(-1).copy()).to(dev)
+        out = t.zeros(self.world * width, dtype=t.float32, device=dev)
+        dist.all_gather_into_tensor(out, row, group=self.group)
+        host = out.cpu().numpy().reshape(self.world, width)
+        return np.concatenate([host[r, :counts[r] * 10].reshape(-1, 10).view(mine.dtype).reshape(-1)
+                               for r in range(self.world)])
 
     def rebalance(self) -> None:
         """Re-cut the domains from the current positions (collective, host-side: gathers all
