@@ -319,6 +319,12 @@ class Simulator:
         check(_lib.lib().nb_sim_read_tree(self._h, buf.ctypes.data, cap, C.byref(nn), C.byref(rw)))
         return buf[: nn.value].copy(), float(rw.value)
 
+    def tree_node_count(self) -> int:
+        """TreeSim: number of octants of the tree the last step built (no copy of the tree)."""
+        nn, rw = C.c_size_t(), C.c_float()
+        check(_lib.lib().nb_sim_read_tree(self._h, None, 0, C.byref(nn), C.byref(rw)))
+        return int(nn.value)
+
     def destroy(self) -> None:
         if self._h and not self._borrowed:
             _lib.lib().nb_sim_destroy(self._h)
