@@ -60,9 +60,10 @@ def cpu_baseline(nb, init_floats, n, target_seconds=12.0):
                       f"step would take {secs / reps * n / m * 1e3:.0f} ms"}
 
 
-def tree_leg(nb, np, n, theta, seed, steps, device):
-    """One Barnes-Hut configuration: ms/step over `steps` steps after 5 warm-up steps (HIP events
-    around the whole steps and around the walk kernel alone), visit / accept counts of one step."""
+def tree_leg(nb, np, n, theta, seed, steps, device, warmup):
+    """One Barnes-Hut configuration: ms/step over `steps` steps after `warmup` untimed steps (the
+    clock needs ~50 ms of back-to-back work to settle, as for the headline; HIP events around the
+    whole steps and around the walk kernel alone), visit / accept counts of one step."""
     sp = nb.SimParams(particle_num=n, g=G, e=E, dt=DT)
     init = nb.inits.uniform_init(sp, seed=seed)
     sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(theta), init, nb.Placement(device_id=device))
@@ -71,7 +72,7 @@ def tree_leg(nb, np, n, theta, seed, steps, device):
     sim.wait()
     c = sim.debug_buffer("counters", np.uint64).copy()
     sim.set_tuning("tree_count_visits", 0)
-    for _ in range(5):
+    for _ in range(warmup):
         sim.encode()
     sim.wait()
     t0 = time.perf_counter()
@@ -81,7 +82,7 @@ def tree_leg(nb, np, n, theta, seed, steps, device):
     sim.destroy()
     accepted = float(c[1]) / n
     walk_tflops = FLOP_PER_PAIR * float(c[1]) / (ms_walk * 1e-3) / 1e12
-    return {"bodies": n, "theta": theta, "init": f"uniform_init seed {seed}", "steps": steps,
+    return {"bodies": n, "theta": theta, "init": f"uniform_init seed {seed}", "steps": steps, "warmup": warmup,
             "ms_per_step": wall / steps * 1e3, "ms_per_step_events": ms_total / steps,
             "walk_ms": ms_walk, "build_ms": ms_total / steps - ms_walk,
             "bodies_per_s": n * steps / wall,
@@ -261,8 +262,8 @@ def main():
             # Barnes-Hut beside the headline, measured in the same run: BASELINE configs[2]
             # (1,048,576 bodies, theta 0.5) and the reference's own headless configuration
             # (src/bin/headless.rs:15-27: 4,000,000 bodies, theta 0.75, uniform_init)
-            out["tree_1m_theta05"] = tree_leg(nb, np, 1 << 20, 0.5, 3, 20, local_rank)
-            out["tree_4m_theta075_headless"] = tree_leg(nb, np, 4000000, 0.75, 0, 10, local_rank)
+            out["tree_1m_theta05"] = tree_leg(nb, np, 1 << 20, 0.5, 3, 40, local_rank, 60)
+            out["tree_4m_theta075_headless"] = tree_leg(nb, np, 4000000, 0.75, 0, 20, local_rank, 20)
         print(json.dumps(out), flush=True)
 
     sim.destroy()

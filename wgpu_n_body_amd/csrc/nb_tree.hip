@@ -783,7 +783,9 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
-    const WalkRoots roots = roots_dev ? *roots_dev : roots_arg;  // (device-made roots: fixed-stride LET imports)
+    // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
+    // by-value copy of a kernel argument selected at run time lands in scratch memory)
+    const uint32_t n_roots = roots_dev ? roots_dev->count : roots_arg.count;
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -824,8 +826,9 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t sp = 0;
     const uint64_t all = __ballot(valid);
     if (all) {  // the roots, pushed so that roots.id[0] is walked first
-        for (uint32_t k = roots.count; k > 0u; --k) {
-            if (lane0) stack[sp] = StackEntry{roots.id[k - 1u], 1u, (uint32_t)all, (uint32_t)(all >> 32)};
+        for (uint32_t k = n_roots; k > 0u; --k) {
+            const uint32_t rid = roots_dev ? roots_dev->id[k - 1u] : roots_arg.id[k - 1u];
+            if (lane0) stack[sp] = StackEntry{rid, 1u, (uint32_t)all, (uint32_t)(all >> 32)};
             sp += 1;
         }
     }
@@ -1011,14 +1014,17 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
 // may walk its own tree (PART 1) while the imports are on the wire and add them later (PART 2),
 // and gets bit for bit what the one-launch step (PART 0) computes.
 template <int G, bool COUNT, int PART>
-__global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_cells_kernel(
+// (G <= 8: at most 96 VGPRs, so that five waves fit a SIMD -- the compiler lands on 90..100 by itself)
+__global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAVES)) void walk_cells_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots_arg, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
-    const WalkRoots roots = roots_dev ? *roots_dev : roots_arg;  // (device-made roots: fixed-stride LET imports)
+    // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
+    // by-value copy of a kernel argument selected at run time lands in scratch memory)
+    const uint32_t n_roots = roots_dev ? roots_dev->count : roots_arg.count;
     __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1031,9 +1037,13 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
     const uint32_t ib = i0 + lane;
     const bool owner = lane < nvalid;  // lane b < G owns body b: loads it, integrates it at the end
     const uint32_t ic = owner ? ib : i0;
-    const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
-    const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
-    const float xi = drift(p.x, vhx, dt), yi = drift(p.y, vhy, dt), zi = drift(p.z, vhz, dt);
+    float xi, yi, zi;
+    {   // kick + drift (tree.wgsl:105-106); redone after the walk instead of kept in registers
+        const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
+        xi = drift(p.x, kick(v.x, a.x, dt), dt);
+        yi = drift(p.y, kick(v.y, a.y, dt), dt);
+        zi = drift(p.z, kick(v.z, a.z, dt), dt);
+    }
     float bx[G], by[G], bz[G];  // the group's evaluation points, wave-uniform (SGPRs)
 #pragma unroll
     for (int b = 0; b < G; ++b) {
@@ -1059,7 +1069,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
         publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
                                                      fmaxf(fabsf(blz), fabsf(bhz))));
     const float theta2 = theta * theta;
-    const uint32_t root0 = roots.id[0];  // a record every idle lane may read
+    const uint32_t root0 = roots_dev ? roots_dev->id[0] : roots_arg.id[0];  // a record every idle lane may read
     const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
     CellEnt *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
@@ -1076,10 +1086,11 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
 #endif
 
     for (uint32_t set = 0; set < 2u; ++set) {
-        const uint32_t r_lo = set == 0u ? 0u : split, r_hi = set == 0u ? min(split, roots.count) : roots.count;
+        const uint32_t r_lo = set == 0u ? 0u : split, r_hi = set == 0u ? min(split, n_roots) : n_roots;
         if (r_lo >= r_hi) continue;
         uint32_t sp = r_hi - r_lo;
-        if (lane < sp) stack[lane] = CellEnt{roots.id[r_lo + lane], group_mask};
+        if (lane < sp)
+            stack[lane] = CellEnt{roots_dev ? roots_dev->id[r_lo + lane] : roots_arg.id[r_lo + lane], group_mask};
         __builtin_amdgcn_wave_barrier();
         float ax[G], ay[G], az[G];
 #pragma unroll
@@ -1240,7 +1251,10 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, NB_WALK_WAVES) void walk_
     }
     const float gdt = g * dt;
     const float fx = tx * gdt, fy = ty * gdt, fz = tz * gdt;
-    posm_dst[ib] = float4{xi, yi, zi, p.w};
+    // the same loads and the same operations as before the walk: bit for bit the same half kick
+    const float4 p = posm_src[ib], v = vel_src[ib], a = acc_src[ib];
+    const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
+    posm_dst[ib] = float4{drift(p.x, vhx, dt), drift(p.y, vhy, dt), drift(p.z, vhz, dt), p.w};
     vel_dst[ib] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
     acc_dst[ib] = float4{fx, fy, fz, 0.f};
 }
