@@ -105,7 +105,10 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
                                                               uint32_t n_src, uint32_t *__restrict__ bound_bits,
                                                               uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ idx,
-                                                              uint32_t *__restrict__ hist, uint32_t nblocks) {
+                                                              uint32_t *__restrict__ hist, uint32_t nblocks,
+                                                              uint32_t items) {
+    // (items = kSortItems: a workgroup is a sort tile and leaves its first-digit histogram; the
+    // counting sort of small problems needs no histogram and takes items = 1: more, shorter workgroups)
     __shared__ uint32_t s_hist[256];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -114,8 +117,8 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
     const float bound = fmaxf(1.0f, __uint_as_float(bmax));  // never below 1.0, tree.rs:427-433
     if (blockIdx.x == 0 && threadIdx.x == 0 && bound_src != bound_bits) *bound_bits = __float_as_uint(bound);
     const float root_w = bound * 2.0f;  // root width, tree.rs:465
-    for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = blockIdx.x * kSortTile + c * kSortThreads + threadIdx.x;
+    for (uint32_t c = 0; c < items; ++c) {
+        const uint32_t i = (blockIdx.x * items + c) * kSortThreads + threadIdx.x;
         if (i >= n) break;
         const float4 p = posm[i];
         float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
         atomicAdd(&s_hist[(uint32_t)key & 255u], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];  // bin-major
+    if (hist) hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];  // bin-major
 }
 
 // ---- 3. radix sort (LSD, 8-bit digits, pairs) ---------------------------------------------------
@@ -313,6 +316,67 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             keys_out[dst] = k;
             vals_out[dst] = s_val[j];
         }
+    }
+}
+
+// ---- 3c. small problems: the whole sort in ONE launch, by counting ------------------------------
+// Up to kRankSortMax bodies a step is bound by its chain of dependent launches (a trivial kernel
+// costs ~4.3 us end to end; the radix sort is sixteen of them), not by work.  There the sorted
+// position of a body is simply COUNTED: rank(i) = #{ j : (key_j, j) < (key_i, i) } -- the all-pairs
+// pattern of the force kernel, on integers: N^2 64-bit compares (6.7e7 at 8,192 bodies, a few
+// microseconds on 1,024 SIMDs), ties broken by source index exactly as the stable radix sort breaks
+// them.  A workgroup owns 64 bodies; its 16 waves split the j range, each staging its slice in LDS;
+// (key_j, j) < (key_i, i) is evaluated as key_j < key_i + [j < i], one compare per pair once a
+// wave's j slice lies entirely below or above its bodies.
+constexpr uint32_t kRankSortMax = 16384;
+constexpr uint32_t kRankWaves = 16;
+constexpr int kRankUnroll = 32;
+
+// (Two workgroups per tile with a ticket for the last to add up and scatter, and the j slices staged
+// in LDS instead of read through the scalar cache, were both measured slower.)
+__global__ __launch_bounds__(64 * kRankWaves) void rank_sort_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                                                    uint64_t *__restrict__ keys_out,
+                                                                    uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_cnt[kRankWaves][64];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t i0 = blockIdx.x * 64u, i = i0 + lane;
+    const uint64_t ki = i < n ? keys[i] : ~0ull;
+    const uint32_t per = (n + kRankWaves - 1u) / kRankWaves;
+    const uint32_t j_lo = min(wave * per, n), j_hi = min(j_lo + per, n);
+    uint32_t count = 0;
+    // (kRankUnroll keys per round of scalar loads -- wave-uniform addresses go through the scalar
+    // cache; a round costs one load latency, so the rounds are made long)
+#define NB_COUNT_RANGE(A, B, CMP)                                   \
+    {                                                               \
+        const uint64_t *kp = keys + (A), *ke = keys + (B);          \
+        for (; kp + kRankUnroll <= ke; kp += kRankUnroll) {         \
+            uint64_t kk[kRankUnroll];                               \
+            _Pragma("unroll") for (int u = 0; u < kRankUnroll; ++u) kk[u] = kp[u]; \
+            _Pragma("unroll") for (int u = 0; u < kRankUnroll; ++u) count += (kk[u] CMP ki) ? 1u : 0u; \
+        }                                                           \
+        for (; kp < ke; ++kp) count += (*kp CMP ki) ? 1u : 0u;      \
+    }
+    // j below the workgroup's bodies: (key_j, j) < (key_i, i)  <=>  key_j <= key_i
+    const uint32_t below_end = min(j_hi, i0);
+    if (j_lo < below_end) NB_COUNT_RANGE(j_lo, below_end, <=)
+    // the workgroup's own 64 bodies: per-lane tie-break
+    const uint32_t own_lo = max(j_lo, i0), own_hi = min(j_hi, min(i0 + 64u, n));
+    for (uint32_t j = own_lo; j < own_hi; ++j) {
+        const uint64_t kj = keys[j];
+        count += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+    }
+    // j above: key_j < key_i
+    const uint32_t above_lo = max(j_lo, min(i0 + 64u, n));
+    if (above_lo < j_hi) NB_COUNT_RANGE(above_lo, j_hi, <)
+#undef NB_COUNT_RANGE
+    s_cnt[wave][lane] = count;
+    __syncthreads();
+    if (wave == 0u && i < n) {
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kRankWaves; ++w) rank += s_cnt[w][lane];
+        keys_out[rank] = ki;
+        order[rank] = i;
     }
 }
 
@@ -529,7 +593,9 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
     const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ depth_base,
     const float4 *__restrict__ posm, uint32_t *__restrict__ int_slot, uint32_t *__restrict__ leaf_id,
     uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
-    Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds) {
+    Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds, const uint32_t *__restrict__ order,
+    const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in, float4 *__restrict__ vel_out,
+    float4 *__restrict__ acc_out) {
     __shared__ uint32_t s_cnt[4][kMaxDepth + 1], s_run[kMaxDepth + 1], s_scan[4];
     __shared__ Moments s_wave[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -560,6 +626,11 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
             const float4 p = posm[k];
             const double m = (double)p.w;
             item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
+            if (vel_in) {  // the rest of sort_particles (tree.rs:564-602): velocities and accelerations
+                const uint32_t src = order[k];
+                vel_out[k] = vel_in[src];
+                acc_out[k] = acc_in[src];
+            }
         }
         Moments mom_total;
         const Moments mom0 = mom_run + block_scan_moments(item, s_wave, &mom_total);  // (syncs)
@@ -1791,7 +1862,7 @@ class TreeSim final : public SimBase {
                 NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));
                 hipLaunchKernelGGL(let_global_bound_kernel, dim3(1), dim3(1), 0, stream, let_meta, let_world,
                                    scalars + 0);
-                if (int rc = enqueue_build(true)) return rc;
+                if (int rc = enqueue_build(true, true)) return rc;  // (a LET rank's velocities never travel)
                 // every peer's export starts with the root in slot 0
                 std::vector<uint32_t> ones(let_world, 1u);
                 ones[let_rank] = 0u;
@@ -2017,13 +2088,15 @@ class TreeSim final : public SimBase {
             return NB_ERR_INVALID;
         }
         if (!build_done)
-            if (int rc = enqueue_build(false)) return rc;
+            if (int rc = enqueue_build(false, place.world == 1)) return rc;
         build_done = false;
         return enqueue_walk(own_root());
     }
 
     // external_bound: the root cube is already in scalars[0] (LET: the max over all ranks)
-    int enqueue_build(bool external_bound) {
+    // with_va: also reorder velocities and accelerations (they are complete: not a sharded host
+    // that still gathers them while the tree is built)
+    int enqueue_build(bool external_bound, bool with_va = false) {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
         uint32_t *depth_base = scalars + 16;  // kMaxDepth + 2 entries
@@ -2044,25 +2117,37 @@ class TreeSim final : public SimBase {
             }
         }
         bound_from_walk = false;
-        hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
-                           n_src, bound_bits, keys[0], idx[0], hist, sort_blocks);
-        // 3: sort (key, index) by key: 8 passes of 8 bits
+        const bool rank_sort = n <= kRankSortMax && sort_mode == 1;
+        if (rank_sort)
+            hipLaunchKernelGGL(morton_kernel, dim3((n + kSortThreads - 1) / kSortThreads), dim3(kSortThreads), 0, stream,
+                               posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u);
+        else
+            hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
+                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, kSortItems);
         int kb = 0;
-        for (uint32_t ps = 0; ps < 8; ++ps) {
-            if (ps)  // (the first digit's tile histograms come with the keys)
-                hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, keys[kb],
-                                   n, 8u * ps, hist, sort_blocks);
-            if (sort_blocks <= kSortInlineScanBlocks) {
-                hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
-                                   sort_blocks);
-            } else {
-                hipLaunchKernelGGL(bin_scan_kernel, dim3(256), b256, 0, stream, hist, sort_blocks, totals);
-                hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
-                                   sort_blocks);
+        if (rank_sort) {
+            // 3c: the sorted position of every body counted in one launch
+            hipLaunchKernelGGL(rank_sort_kernel, dim3((n + 63u) / 64u), dim3(64 * kRankWaves), 0, stream, keys[0], n,
+                               keys[1], idx[1]);
+            kb = 1;
+        } else {
+            // 3: sort (key, index) by key: 8 passes of 8 bits
+            for (uint32_t ps = 0; ps < 8; ++ps) {
+                if (ps)  // (the first digit's tile histograms come with the keys)
+                    hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
+                                       keys[kb], n, 8u * ps, hist, sort_blocks);
+                if (sort_blocks <= kSortInlineScanBlocks) {
+                    hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
+                                       keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
+                                       sort_blocks);
+                } else {
+                    hipLaunchKernelGGL(bin_scan_kernel, dim3(256), b256, 0, stream, hist, sort_blocks, totals);
+                    hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
+                                       keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
+                                       sort_blocks);
+                }
+                kb ^= 1;
             }
-            kb ^= 1;
         }
         uint64_t *skeys = keys[kb];
         order = idx[kb];
@@ -2078,7 +2163,8 @@ class TreeSim final : public SimBase {
                            depth_base, n_nodes, node_cap, status, bound_slots);
         hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, depth_base,
                            posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
-                           rounds);
+                           rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
+        va_gathered = with_va;
         // 6: node contents
         const uint32_t gnodes = (node_cap + 255) / 256;
         hipLaunchKernelGGL(fill_kernel<false>, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
@@ -2094,9 +2180,10 @@ class TreeSim final : public SimBase {
         const int s = cur, d = cur ^ 1;
         uint32_t *status = scalars + 4;
         const dim3 b256(256);
-        if (part != 2)
+        if (part != 2 && !va_gathered)
             hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
                                vel[d], acc[d]);
+        va_gathered = false;
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s.  A walk over the whole state in
         // one launch also leaves max |coord| of the new positions for the next step's root cube.
         const bool whole = part == 0 && !let_world && place.world == 1 && lo == 0 && hi == n;
@@ -2350,7 +2437,7 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
-        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: small problems one launch per digit, 0: always 2-3
+        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: up to 16,384 bodies sorted by counting, 0: always radix
             sort_mode = value != 0 ? 1u : 0u;
             drop_graph();
             return NB_OK;
@@ -2446,6 +2533,7 @@ class TreeSim final : public SimBase {
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1;
     uint32_t *tile_u32 = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
+    bool va_gathered = false;      // the build has already reordered velocities and accelerations
     Moments *tile_mom = nullptr;
     uint32_t cell_tiles = 0;
     bool build_done = false;  // phase 0 of the next step already enqueued
