@@ -19,6 +19,8 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--init", default="uniform")
 ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--g", type=float, default=None)
+ap.add_argument("--dt", type=float, default=None)
 ap.add_argument("--bpw", type=int, default=None, help="bodies per wave of the walk (default: automatic)")
 ap.add_argument("--mode", type=int, default=None, help="walk kernel: 1 cells across the lanes (default), 0 bodies across the lanes")
 ap.add_argument("--group", type=int, default=None, help="bodies per wave of mode 1 (4/8/16)")
@@ -30,6 +32,9 @@ ap.add_argument("--cpu-baseline", action="store_true",
 args = ap.parse_args()
 
 sp = nb.SimParams(particle_num=args.bodies)
+if args.g is not None or args.dt is not None:
+    sp = nb.SimParams(particle_num=args.bodies, g=args.g if args.g is not None else sp.g,
+                      dt=args.dt if args.dt is not None else sp.dt)
 init = getattr(nb.inits, args.init + "_init")(sp, seed=args.seed)
 sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(args.theta), init)
 if args.mode is not None:

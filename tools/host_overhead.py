@@ -52,7 +52,44 @@ def main() -> None:
         print(f"{label:40s} enqueue {t_enq / args.steps * 1e6:7.1f} us/step   "
               f"enqueue+drain {t_all / args.steps * 1e6:7.1f} us/step", flush=True)
         sim.destroy()
+
+    # The LET step (Barnes-Hut, one process per GPU) on one rank with its collectives forced on: the
+    # host cost of the protocol with the export counts read on the host every step, and without
+    # (fixed-stride imports, counts consumed on the device) -- RCCL all-gathers of regions 0 and 1
+    # and an all-to-all of zero-length device views either way.
+    from wgpu_n_body_amd.sharded import LetTreeSim
+    LetTreeSim.force_exchange = True
+    spt = nb.SimParams(particle_num=4096, g=1e-6, e=1e-4, dt=0.016)
+    initt = nb.inits.uniform_init(spt, seed=2)
+    for label, asyn in (("LET step, counts read on the host", False), ("LET step, no host read", True)):
+        let = LetTreeSim(spt, 0.5, initt, 0, 1, 0, migrate_every=0, async_exchange=asyn)
+        for _ in range(50):
+            let.encode()
+        let.wait()
+        steps = 500
+        before = let.host_syncs
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            let.encode()
+        t_enq = time.perf_counter() - t0
+        let.wait()
+        t_all = time.perf_counter() - t0
+        print(f"{label:40s} enqueue {t_enq / steps * 1e6:7.1f} us/step   enqueue+drain {t_all / steps * 1e6:7.1f} us/step"
+              f"   host reads per step {(let.host_syncs - before) / steps:.2f}", flush=True)
+        let.destroy()
     dist.destroy_process_group()
+
+    # The one-process runner of the C ABI (nb_runner_create_multi): 8 ranks on this one GPU, 2,048
+    # bodies -- kernels far shorter than the host work, so this is the library's own cost per step
+    # (8 host threads: two launches, 7 event waits, one record each, one host barrier)
+    sp8 = nb.SimParams(particle_num=2048, g=1e-6, e=1e-4, dt=0.016)
+    runner = nb.OfflineHeadless(nb.NaiveSim, sp8, None, lambda p: nb.inits.uniform_init(p, seed=2), device_ids=[0] * 8)
+    runner.step_n(200)
+    t0 = time.perf_counter()
+    runner.step_n(2000)
+    t = time.perf_counter() - t0
+    print(f"{'nb_runner_create_multi, 8 ranks, step_n':40s} {t / 2000 * 1e6:7.1f} us/step", flush=True)
+    runner.destroy()
 
 
 if __name__ == "__main__":

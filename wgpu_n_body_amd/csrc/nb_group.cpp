@@ -23,6 +23,7 @@
 //
 // The same device id may be given several times (ranks sharing a GPU): that is how the path is
 // tested on a one-GPU box, bit for bit the same code.
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -36,26 +37,26 @@
 namespace nb {
 
 namespace {
+// The once-per-step meeting of the rank threads: spin on a generation counter (the step of a rank
+// is tens of microseconds; a condition variable's wake-up costs as much), yield when it drags on.
 class HostBarrier {
    public:
     explicit HostBarrier(int n) : n_(n) {}
     void wait() {
-        std::unique_lock<std::mutex> lk(mu_);
-        const uint64_t gen = gen_;
-        if (++count_ == n_) {
-            count_ = 0;
-            ++gen_;
-            cv_.notify_all();
-        } else {
-            cv_.wait(lk, [&] { return gen_ != gen; });
+        const uint64_t gen = gen_.load(std::memory_order_acquire);
+        if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            count_.store(0, std::memory_order_relaxed);
+            gen_.store(gen + 1, std::memory_order_release);
+            return;
         }
+        for (uint32_t spins = 0; gen_.load(std::memory_order_acquire) == gen; ++spins)
+            if (spins > 2000u) std::this_thread::yield();
     }
 
    private:
-    std::mutex mu_;
-    std::condition_variable cv_;
-    int n_, count_ = 0;
-    uint64_t gen_ = 0;
+    const int n_;
+    std::atomic<int> count_{0};
+    std::atomic<uint64_t> gen_{0};
 };
 }  // namespace
 
