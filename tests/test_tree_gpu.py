@@ -151,6 +151,37 @@ def test_every_walk_shape_against_oracle(gpu, oracle, kind, n, theta, g, dt):
             assert np.abs(r["dst"][:, 6:9] - first["dst"][:, 6:9]).max() <= 3e-6 * scale, shape
 
 
+@pytest.mark.parametrize("core,spread", [(0.5, 2e-3), (0.9, 3e-4)])
+def test_deep_clustered_tree_against_oracle(gpu, oracle, core, spread):
+    """A dense core inside a sparse halo: a tree 14+ levels deep whose frontier is far wider than
+    on uniform data (the reference's fixed 64-entry stack overflows on this kind of input, SURVEY
+    A14 D3).  Exercises the walk's stack discipline -- batch width limited by the free space, down
+    to single-cell depth-first batches -- and the build on long common key prefixes."""
+    nb = gpu
+    n = 24000
+    rng = np.random.default_rng(7)
+    s = make_state("uniform", n, 321)
+    k = int(core * n)
+    s[:k, 0:3] = (np.float32(0.3) + rng.normal(0.0, spread, size=(k, 3))).astype(np.float32)
+    s[:, 3:6] *= np.float32(0.01)
+    ref = oracle.tree_step_f32(s, G, E, DT, 0.5, flags=oracle.INTENDED)
+    depth_proxy = ref["stats"]["high_water"]
+    assert depth_proxy > 40                       # far beyond the uniform case (~22 at this size)
+    for shape in ({"tree_walk_mode": 1, "tree_walk_group": 8}, {"tree_walk_mode": 1, "tree_walk_group": 16},
+                  {"tree_walk_mode": 0}):
+        r = run_tree(gpu, s, 0.5, 1, tuning=shape)
+        assert not r["status"].any(), shape
+        check_tree(r["tree"], r["root_width"], r["order"], ref["tree"], ref["root_width"], ref["order"])
+        assert np.isfinite(r["dst"]).all()
+        assert np.array_equal(bits(r["dst"][:, 0:3]), bits(ref["dst"][:, 0:3]))
+        # (inside the core a body's force is a sum of large, nearly cancelling neighbour terms: the
+        # order of summation shows at a few 1e-5 -- in the oracle's sequential fp32 sum as well)
+        err = rel_err(r["dst"][:, 6:9], ref["dst"][:, 6:9])
+        assert np.median(err) < 2e-4 and np.percentile(err, 99) < 5e-3 and err.max() < 5e-2, (shape, np.median(err))
+        assert abs(int(r["counters"][0]) - ref["stats"]["visits"]) <= max(2, 1e-5 * ref["stats"]["visits"]), shape
+        assert abs(int(r["counters"][1]) - ref["stats"]["accepted"]) <= max(2, 1e-5 * ref["stats"]["accepted"]), shape
+
+
 def test_bodies_outside_the_unit_cube_scale_the_root(gpu, oracle):
     s = make_state("uniform", 2000, 61)
     s[:, 0:3] *= 7.5          # bound = max |coord| > 1 -> root_width = 2 * bound (tree.rs:446-451)

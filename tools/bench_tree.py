@@ -24,6 +24,7 @@ ap.add_argument("--dt", type=float, default=None)
 ap.add_argument("--bpw", type=int, default=None, help="bodies per wave of the walk (default: automatic)")
 ap.add_argument("--mode", type=int, default=None, help="walk kernel: 1 cells across the lanes (default), 0 bodies across the lanes")
 ap.add_argument("--group", type=int, default=None, help="bodies per wave of mode 1 (4/8/16)")
+ap.add_argument("--rounds", type=int, default=None, help="256-body rounds per workgroup of the cells kernels")
 ap.add_argument("--sort", type=int, default=None, help="sort: 1 one-sweep (default), 0 three kernels per digit")
 ap.add_argument("--cpu-baseline", action="store_true",
                 help="also time the CPU oracle: the reference's serial BFS build + DFS reorder "
@@ -43,6 +44,8 @@ if args.group is not None:
     sim.set_tuning("tree_walk_group", args.group)
 if args.sort is not None:
     sim.set_tuning("tree_sort_mode", args.sort)
+if args.rounds is not None:
+    sim.set_tuning("tree_cell_rounds", args.rounds)
 if args.bpw is not None:
     sim.set_tuning("tree_walk_bpw", args.bpw)
 sim.set_tuning("tree_count_visits", 1)

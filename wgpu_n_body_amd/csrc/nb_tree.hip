@@ -1678,7 +1678,7 @@ class TreeSim final : public SimBase {
         const size_t nn = n ? n : 1;
         node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
         sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
-        cell_tiles = (uint32_t)(std::min<size_t>(nn, 131072) / 256 + (nn + 1 + kCellTile - 1) / kCellTile + 2);  // capacity
+        cell_tiles = (uint32_t)std::max({std::min<size_t>(nn, 131072) / 256, std::min<size_t>(nn, 524288) / 512, nn / kCellTile}) + 4;  // capacity
         const size_t npad = n_pad ? n_pad : 256;  // equal-sized slices for the all-gathers
         for (int b = 0; b < 2; ++b) {
             if (int rc = alloc(&posm[b], sizeof(float4) * npad)) return rc;
@@ -2154,7 +2154,10 @@ class TreeSim final : public SimBase {
         sorted_keys = skeys;
         // 4-6a: the step's source permuted into DFS/Morton order (tree.rs:297,315-325), cells from
         // key prefixes, node ids, moment prefixes: A, B, C of section 5b
-        const uint32_t rounds = n <= 131072u ? 1u : kCellTile / 256u;
+        // 256-body rounds per workgroup: small problems are bound by the chain of barriers inside a
+        // workgroup (1 round), large ones by the length of the one-workgroup scan over the tiles (4)
+        uint32_t rounds = n <= 131072u ? 1u : n <= 524288u ? 2u : kCellTile / 256u;
+        if (cell_rounds && ((size_t)n + 256 * cell_rounds) / (256 * cell_rounds) + 1 <= cell_tiles) rounds = cell_rounds;
         const uint32_t ct = (uint32_t)(((size_t)n + 1 + 256 * rounds - 1) / (256 * rounds));  // covers prefix[n] too
         const uint32_t cstride = (ct + 3u) & ~3u;  // rows of the tile table, padded to 16 bytes
         hipLaunchKernelGGL(cells_a_kernel, dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys, cpl,
@@ -2437,6 +2440,15 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_cell_rounds") == 0) {  // 256-body rounds per workgroup of cells_a / cells_c; 0 = automatic
+            if (value < 0 || value > 4) {
+                set_error("tree_cell_rounds must be 0 .. 4");
+                return NB_ERR_INVALID;
+            }
+            cell_rounds = (uint32_t)value;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: up to 16,384 bodies sorted by counting, 0: always radix
             sort_mode = value != 0 ? 1u : 0u;
             drop_graph();
@@ -2530,7 +2542,7 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
-    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1;
+    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0;
     uint32_t *tile_u32 = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
