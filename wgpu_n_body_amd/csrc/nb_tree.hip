@@ -380,6 +380,105 @@ __global__ __launch_bounds__(64 * kRankWaves) void rank_sort_kernel(const uint64
     }
 }
 
+// ---- 3d. large problems: radix passes over the HIGH digits only, then a fix-up of the ties --------
+// With N bodies in a cube, two bodies share the top 8 P bits of their keys only if they sit in the
+// same cell of level ~8P/3: for P = 4 that is one of 2^31 cells, so after four stable passes over
+// bits 32..62 all but a few hundred of a million uniform bodies are already in their final place,
+// and the others form short RUNS of equal high bits (in source-index order, the passes being
+// stable) that only need sorting among themselves by the low bits.  That replaces the four low
+// passes (12 launches) by two: runs_mark_kernel lists the runs, runs_sort_kernel sorts each in
+// place -- a wave per run of <= 64 bodies (rank by counting, keys exchanged by shuffles), a
+// workgroup per longer run (counting against the whole run, out of place into the idle ping-pong
+// buffer, then copied back).  Any input is sorted correctly; a dense cluster just costs O(L^2)
+// compares for a run of L.  The result is the stable full-key order, bit for bit the 8-pass sort's.
+constexpr uint32_t kRunWave = 64;
+
+__global__ __launch_bounds__(256) void runs_mark_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                                        uint32_t low_bits, uint32_t *__restrict__ short_list,
+                                                        uint32_t *__restrict__ long_list,
+                                                        uint32_t *__restrict__ counts) {
+    // (one global atomic per workgroup and list: tens of thousands of returning atomics on one word
+    // serialise at ~7 ns each)
+    __shared__ uint32_t s_n[2], s_base[2];
+    if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    int kind = -1;  // 0: first of a short run, 1: first of a long run
+    if (k + 1u < n) {
+        const uint64_t hi = keys[k] >> low_bits;
+        const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
+        if (first && (keys[k + 1u] >> low_bits) == hi)
+            // sorted by the high bits: if the body 64 places on still shares them, so do all in between
+            kind = (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) ? 1 : 0;
+    }
+    uint32_t local = 0;
+    if (kind >= 0) local = atomicAdd(&s_n[kind], 1u);
+    __syncthreads();
+    if (threadIdx.x < 2u && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_n[threadIdx.x]);
+    __syncthreads();
+    if (kind == 0) short_list[s_base[0] + local] = k;
+    if (kind == 1) long_list[s_base[1] + local] = k;
+}
+
+__global__ __launch_bounds__(256) void runs_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
+                                                        uint32_t n, uint32_t low_bits,
+                                                        const uint32_t *__restrict__ short_list,
+                                                        const uint32_t *__restrict__ long_list,
+                                                        const uint32_t *__restrict__ counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_short = counts[0], n_long = counts[1];
+    // short runs: one wave each
+    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < n_short; r += gridDim.x * 4u) {
+        const uint32_t start = short_list[r];
+        const uint64_t hi = keys[start] >> low_bits;
+        const uint32_t pos = start + lane;
+        const bool in = pos < n && (keys[min(pos, n - 1u)] >> low_bits) == hi;   // (a run is < 64 long here)
+        const uint32_t len = (uint32_t)__popcll(__ballot(in));
+        const uint64_t ki = in ? keys[pos] : ~0ull;
+        const uint32_t vi = in ? vals[pos] : 0u;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint64_t kj = ((uint64_t)(uint32_t)__shfl((int)(ki >> 32), (int)j) << 32) |
+                                (uint32_t)__shfl((int)(uint32_t)ki, (int)j);
+            rank += (kj < ki || (kj == ki && j < lane)) ? 1u : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (in) {
+            keys[start + rank] = ki;
+            vals[start + rank] = vi;
+        }
+    }
+    // long runs: one workgroup each
+    for (uint32_t r = blockIdx.x; r < n_long; r += gridDim.x) {
+        const uint32_t start = long_list[r];
+        const uint64_t hi = keys[start] >> low_bits;
+        uint32_t lo_s = start + kRunWave, hi_s = n;   // first position past the run: binary search
+        while (lo_s < hi_s) {
+            const uint32_t mid = lo_s + ((hi_s - lo_s) >> 1);
+            if ((keys[mid] >> low_bits) == hi) lo_s = mid + 1u; else hi_s = mid;
+        }
+        const uint32_t len = lo_s - start;
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint64_t ki = keys[start + i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < len; ++j) {
+                const uint64_t kj = keys[start + j];
+                rank += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+            }
+            alt_keys[start + rank] = ki;
+            alt_vals[start + rank] = vals[start + i];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+            keys[start + i] = alt_keys[start + i];
+            vals[start + i] = alt_vals[start + i];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- 4. gather into sorted (DFS) order ----------------------------------------------------------
 // positions/masses first (the build needs them), velocities/accelerations separately (only the
 // walk needs them): on several GPUs the second pair is still being all-gathered while the build runs
@@ -527,9 +626,11 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
                                                           uint32_t *__restrict__ depth_base,
                                                           uint32_t *__restrict__ n_nodes, uint32_t cap,
                                                           uint32_t *__restrict__ status,
-                                                          uint32_t *__restrict__ bound_slots) {
+                                                          uint32_t *__restrict__ bound_slots,
+                                                          uint32_t *__restrict__ run_counts) {
     __shared__ uint32_t s_total[kCellRows];
     if (threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
+    if (threadIdx.x < 2u) run_counts[threadIdx.x] = 0u;           // the next step's sort fix-up lists
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     // a wave takes a row in chunks of 256 tiles: every lane 4 consecutive tiles (one 16-byte
     // access; rows are padded to a multiple of 4 words), a wave scan of the lane sums, a carry
@@ -1693,6 +1794,8 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&d_aos, sizeof(nb_particle) * nn)) return rc;
         if (int rc = alloc(&hist, sizeof(uint32_t) * 256 * (size_t)sort_blocks)) return rc;
         if (int rc = alloc(&totals, sizeof(uint32_t) * 256)) return rc;
+        if (int rc = alloc(&run_short, sizeof(uint32_t) * (nn / 2 + 2))) return rc;
+        if (int rc = alloc(&run_long, sizeof(uint32_t) * (nn / kRunWave + 2))) return rc;
         if (int rc = alloc(&cpl, nn + 2)) return rc;
         if (int rc = alloc(&int_slot, sizeof(uint32_t) * nn)) return rc;
         if (int rc = alloc(&tile_u32, sizeof(uint32_t) * kCellRows * ((size_t)cell_tiles + 4))) return rc;
@@ -2121,7 +2224,7 @@ class TreeSim final : public SimBase {
         if (rank_sort)
             hipLaunchKernelGGL(morton_kernel, dim3((n + kSortThreads - 1) / kSortThreads), dim3(kSortThreads), 0, stream,
                                posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u);
-        else
+        else  // (the first-digit histogram it leaves is used when all eight passes run)
             hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
                                n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, kSortItems);
         int kb = 0;
@@ -2131,9 +2234,19 @@ class TreeSim final : public SimBase {
                                keys[1], idx[1]);
             kb = 1;
         } else {
-            // 3: sort (key, index) by key: 8 passes of 8 bits
-            for (uint32_t ps = 0; ps < 8; ++ps) {
-                if (ps)  // (the first digit's tile histograms come with the keys)
+            // 3 / 3d: stable radix passes of 8 bits -- all eight, or (sort_mode 1) only the top `hp` digits
+            // followed by the fix-up of the runs that tie there; hp such that a cell of that level
+            // holds 1/64 body on average (8 hp >= log2(64 N))
+            uint32_t hp = 8;
+            if (sort_mode == 1) {
+                uint32_t bits = 6;
+                while ((1ull << bits) < 64ull * n) ++bits;
+                hp = std::min(8u, std::max(3u, (bits + 7u) / 8u));
+            }
+            const uint32_t first = 8u - hp;  // passes first .. 7, digits at bit 8 * pass
+            for (uint32_t ps = first; ps < 8; ++ps) {
+                // (the lowest digit's tile histograms come with the keys when all eight passes run)
+                if (ps != 0u)
                     hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
                                        keys[kb], n, 8u * ps, hist, sort_blocks);
                 if (sort_blocks <= kSortInlineScanBlocks) {
@@ -2147,6 +2260,13 @@ class TreeSim final : public SimBase {
                                        sort_blocks);
                 }
                 kb ^= 1;
+            }
+            if (first) {
+                uint32_t *run_counts = scalars + 12;  // zeroed by the previous step's cells_scan_kernel
+                hipLaunchKernelGGL(runs_mark_kernel, dim3(g256), b256, 0, stream, keys[kb], n, 8u * first, run_short,
+                                   run_long, run_counts);
+                hipLaunchKernelGGL(runs_sort_kernel, dim3(1024), b256, 0, stream, keys[kb], idx[kb], keys[kb ^ 1],
+                                   idx[kb ^ 1], n, 8u * first, run_short, run_long, run_counts);
             }
         }
         uint64_t *skeys = keys[kb];
@@ -2163,7 +2283,7 @@ class TreeSim final : public SimBase {
         hipLaunchKernelGGL(cells_a_kernel, dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys, cpl,
                            tile_u32, tile_mom, cstride, rounds, status);
         hipLaunchKernelGGL(cells_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
-                           depth_base, n_nodes, node_cap, status, bound_slots);
+                           depth_base, n_nodes, node_cap, status, bound_slots, scalars + 12);
         hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, depth_base,
                            posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
                            rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
@@ -2449,7 +2569,8 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
-        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: up to 16,384 bodies sorted by counting, 0: always radix
+        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: counting sort (<= 16,384 bodies) / high digits + fix-up;
+                                                        // 0: always the full 8-pass radix sort
             sort_mode = value != 0 ? 1u : 0u;
             drop_graph();
             return NB_OK;
@@ -2543,7 +2664,7 @@ class TreeSim final : public SimBase {
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0;
-    uint32_t *tile_u32 = nullptr;
+    uint32_t *tile_u32 = nullptr, *run_short = nullptr, *run_long = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
     Moments *tile_mom = nullptr;
