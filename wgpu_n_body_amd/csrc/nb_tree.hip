@@ -657,18 +657,25 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
         }
         if (lane == 0u) s_total[r] = carry;
     }
-    const uint32_t seg = (ntiles + 63u) / 64u;
-    const uint32_t lo = min(lane * seg, ntiles), hi = min(lo + seg, ntiles);
-    if (wave == 15u) {  // the moments, strictly in tile order per lane segment, then in lane order
+    {   // the moments, by all 1,024 threads in a fixed order: thread t sums the tiles [t S, (t+1) S) in
+        // order, the threads' sums are scanned by wave (fixed shuffle tree) and the waves' totals
+        // added in wave order -- deterministic whatever the launch timing
+        __shared__ Moments s_wtot[16];
+        const uint32_t per = (ntiles + 1023u) / 1024u;
+        const uint32_t t_lo = min(threadIdx.x * per, ntiles), t_hi = min(t_lo + per, ntiles);
         Moments sum{0, 0, 0, 0};
-        for (uint32_t i = lo; i < hi; ++i) sum = sum + tile_mom[i];
+        for (uint32_t i = t_lo; i < t_hi; ++i) sum = sum + tile_mom[i];
         Moments x = sum;
         for (int o = 1; o < 64; o <<= 1) {
             Moments y{__shfl_up(x.x, o), __shfl_up(x.y, o), __shfl_up(x.z, o), __shfl_up(x.m, o)};
             if ((int)lane >= o) x = x + y;
         }
-        Moments run{x.x - sum.x, x.y - sum.y, x.z - sum.z, x.m - sum.m};
-        for (uint32_t i = lo; i < hi; ++i) {
+        if (lane == 63u) s_wtot[wave] = x;
+        __syncthreads();
+        Moments run{0, 0, 0, 0};
+        for (uint32_t w = 0; w < wave; ++w) run = run + s_wtot[w];
+        run = run + Moments{x.x - sum.x, x.y - sum.y, x.z - sum.z, x.m - sum.m};
+        for (uint32_t i = t_lo; i < t_hi; ++i) {
             const Moments v = tile_mom[i];
             tile_mom[i] = run;
             run = run + v;
