@@ -16,7 +16,7 @@ for p in ("p1", "p2"):
     f = glob.glob("$OUT/%s/**/*_counter_collection.csv" % p, recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "walk_" in r["Kernel_Name"] and "true" not in r["Kernel_Name"].split("(")[0]:
+        if "walk_" in r["Kernel_Name"] and "true" not in r["Kernel_Name"].split(">(")[0]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         print("%-24s %16.0f  (avg of %d launches)" % (k, sum(v) / len(v), len(v)))
