@@ -321,15 +321,19 @@ int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
 
 /* The same constructor over SEVERAL GPUs of this process (no reference counterpart: the reference
  * owns one adapter, offline_headless.rs:22-31; this is SURVEY 8(b)'s `device_ids, n_devices` form).
- * All-pairs only: rank r owns the contiguous body range [r per, (r+1) per), per =
+ * All-pairs: rank r owns the contiguous body range [r per, (r+1) per), per =
  * nb_shard_bodies_per_rank(N, n_devices), on device_ids[r]; every device keeps both position/mass
  * buffers in full, and the kernel that finishes a rank's step stores the rank's new
  * float4{x,y,z,m} slice into every peer's next-step buffer through peer access (one slice per
  * xGMI link), ordered by one HIP event per rank and step -- no host copy, no collective library.
+ * Barnes-Hut: replicated tree, partitioned walk -- every device holds the full
+ * state and builds the identical octree, walks its range of the sorted bodies, and copies its new
+ * position / velocity / acceleration slices into every peer's arrays (peer copies on its stream,
+ * two events per rank and step); bit for bit the single TreeSim.  (Morton domains + LET exchange,
+ * which also shards the build, runs one process per GPU: nb_placement, NB_PHASE_LET_*.)
  * One host thread per rank inside the library; the caller stays single-threaded and every call
  * below is synchronous as on one device.  A device id may repeat (ranks sharing a GPU).  n_devices
- * == 1 is nb_runner_create.  NB_ERR_UNSUPPORTED for a TreeSim: several-GPU Barnes-Hut runs one
- * process per GPU (nb_placement, NB_PHASE_LET_*). */
+ * == 1 is nb_runner_create. */
 int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params,
                            const nb_add_params *add_params, nb_init_fn init, void *user,
                            const int *device_ids, int n_devices);

@@ -133,7 +133,40 @@ def test_multi_runner_argument_errors(gpu):
     sp = nb.SimParams(particle_num=64)
     with pytest.raises(nb.NBodyError):      # a device that does not exist
         nb.OfflineHeadless(nb.NaiveSim, sp, None, lambda p: nb.inits.uniform_init(p), device_ids=[0, 99])
-    with pytest.raises(nb.NBodyError) as ei:  # Barnes-Hut on several GPUs is one process per GPU
-        nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(0.5), lambda p: nb.inits.uniform_init(p),
-                           device_ids=[0, 0])
-    assert ei.value.code == 5
+
+
+@pytest.mark.parametrize("n,world,theta", [(20000, 4, 0.5), (4097, 3, 0.75), (1 << 17, 8, 0.5), (300, 5, 0.5)])
+def test_multi_runner_tree_is_the_single_tree_bit_for_bit(gpu, n, world, theta):
+    """nb_runner_create_multi with TreeSimParams: replicated tree, partitioned walk, each rank's
+    position / velocity / acceleration slices copied into every peer's arrays.  `world` ranks on the
+    one GPU of this box (the code path of `world` GPUs, minus the links) against one TreeSim, whose
+    parity with the oracle the tests of test_tree_gpu.py hold: every bit, after several steps --
+    a slice that landed late, early or not at all would change the next build."""
+    nb = gpu
+    sp = nb.SimParams(particle_num=n)
+    init = nb.inits.disc_init(sp, seed=n) if n == 20000 else nb.inits.uniform_init(sp, seed=n)
+    add = nb.AddParams.TreeSimParams(theta)
+    multi = nb.OfflineHeadless(nb.TreeSim, sp, add, lambda _p: init, device_ids=[0] * world)
+    one = nb.OfflineHeadless(nb.TreeSim, sp, add, lambda _p: init)
+    multi.step()
+    one.step()
+    multi.step_n(5)
+    one.step_n(5)
+    assert multi.step_num() == one.step_num() == 6
+    a, b = nb.as_floats(multi.read_particles()), nb.as_floats(one.read_particles())
+    multi.destroy()
+    one.destroy()
+    assert np.isfinite(b).all() and np.array_equal(bits(a), bits(b))
+
+
+def test_cli_tree_on_several_devices(gpu, tmp_path):
+    """The C++ host (headless.cpp) stepping Barnes-Hut on --devices 0,0,0: same snapshot as one device."""
+    from wgpu_n_body_amd.snapshot import load_snapshot
+    common = ["--sim", "tree", "--theta", 0.5, "--n", 50000, "--init", "disc", "--seed", 5, "--steps", 4]
+    os.makedirs(os.path.join(tmp_path, "m"))
+    os.makedirs(os.path.join(tmp_path, "s"))
+    _t, pm = run_cli(common + ["--devices", "0,0,0"], os.path.join(tmp_path, "m"))
+    _t, ps = run_cli(common, os.path.join(tmp_path, "s"))
+    _sp, a, sa = load_snapshot(pm)
+    _sp, b, sb = load_snapshot(ps)
+    assert sa == sb == 4 and np.array_equal(bits(gpu.as_floats(a)), bits(gpu.as_floats(b)))

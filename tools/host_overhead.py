@@ -91,6 +91,20 @@ def main() -> None:
     print(f"{'nb_runner_create_multi, 8 ranks, step_n':40s} {t / 2000 * 1e6:7.1f} us/step", flush=True)
     runner.destroy()
 
+    # Barnes-Hut through the same runner (replicated tree, partitioned walk, peer copies): `world` ranks
+    # on this ONE GPU -- the builds are done `world` times on the same device, so the step time here
+    # is an upper bound of the host protocol's cost, not a scaling figure
+    for n, world in ((8192, 1), (8192, 8), (1 << 20, 1), (1 << 20, 2), (1 << 20, 8)):
+        spn = nb.SimParams(particle_num=n, g=1e-6, e=1e-4, dt=0.016)
+        runner = nb.OfflineHeadless(nb.TreeSim, spn, nb.AddParams.TreeSimParams(0.5),
+                                    lambda p: nb.inits.uniform_init(p, seed=3), device_ids=[0] * world)
+        runner.step_n(30)
+        t0 = time.perf_counter()
+        runner.step_n(100)
+        t = time.perf_counter() - t0
+        print(f"{'nb_runner_create_multi tree, n=%d, %d rank(s)' % (n, world):52s} {t / 100 * 1e6:8.1f} us/step", flush=True)
+        runner.destroy()
+
 
 if __name__ == "__main__":
     main()

@@ -355,7 +355,7 @@ class OfflineHeadless:
 
     def __init__(self, sim_type, sim_params: SimParams, add_params: Optional[AddParams],
                  init_fn: InitFn, device_id: int = -1, device_ids: Optional[Sequence[int]] = None):
-        """device_ids: several GPUs of this process (nb_runner_create_multi; all-pairs only): rank r
+        """device_ids: several GPUs of this process (nb_runner_create_multi; all-pairs: body ranges + peer stores, TreeSim: replicated tree + partitioned walk): rank r
         owns a contiguous body range on device_ids[r]; a device id may repeat."""
         L = _lib.lib()
         if add_params is None or add_params.kind != sim_type.KIND:

@@ -4,7 +4,7 @@
 //   headless [--sim naive|tree] [--n N] [--steps S] [--theta T] [--init uniform|disc|spherical]
 //            [--seed K] [--device D | --devices D0,D1,...] [--g G] [--dt DT] [--dump FILE]
 //
-// --devices: the all-pairs step sharded over several GPUs of this process (nb_runner_create_multi);
+// --devices: the step sharded over several GPUs of this process (nb_runner_create_multi; both simulators);
 // a device id may repeat.
 //
 // --dump FILE writes the final state as a snapshot (the layout of

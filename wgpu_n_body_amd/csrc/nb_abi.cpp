@@ -620,15 +620,18 @@ int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params, con
         }
         *out = nullptr;
         if (n_devices == 1) return nb_runner_create(out, sim_params, add_params, init, user, device_ids[0]);
-        if (add_params && add_params->kind != NB_NAIVE_SIM_PARAMS) {
-            set_error("nb_runner_create_multi: the one-process runner shards the all-pairs simulator; several-GPU "
-                      "Barnes-Hut runs one process per GPU (nb_placement / the NB_PHASE_LET_* protocol)");
-            return NB_ERR_UNSUPPORTED;
+        nb_add_params add;
+        add.kind = NB_NAIVE_SIM_PARAMS;
+        add.theta = 0.f;
+        if (add_params) add = *add_params;
+        if (add.kind != NB_NAIVE_SIM_PARAMS && add.kind != NB_TREE_SIM_PARAMS) {
+            set_error("unknown add_params.kind %d", add.kind);
+            return NB_ERR_INVALID;
         }
         std::vector<nb_particle> host(sim_params->particle_num);
         init(sim_params, host.data(), user);  // init_fn(&sim_params) -> Vec<Particle>, once, on the host
         std::unique_ptr<NaiveGroup> g;
-        if (int rc = NaiveGroup::create(g, *sim_params, host.data(), device_ids, n_devices)) return rc;
+        if (int rc = NaiveGroup::create(g, *sim_params, add, host.data(), device_ids, n_devices)) return rc;
         nb_runner *r = new nb_runner();
         r->group = std::move(g);
         *out = r;

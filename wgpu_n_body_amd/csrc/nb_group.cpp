@@ -23,6 +23,15 @@
 //
 // The same device id may be given several times (ranks sharing a GPU): that is how the path is
 // tested on a one-GPU box, bit for bit the same code.
+//
+// Barnes-Hut through the same runner is the replicated-tree scheme of SURVEY 8(e) step 1: every
+// rank holds the full state and builds the identical octree, walks only its range of the sorted
+// bodies, and its new position / velocity / acceleration slices are copied into every peer's
+// arrays (hipMemcpyPeerAsync on the rank's stream) once EVERY rank has finished the step -- a
+// TreeSim's step reads and writes the same arrays, so the copies must not land while a peer still
+// reads them: two events per rank and step ("step finished", "slices pushed").  Bit for bit the
+// single TreeSim.  (The scheme that also shards the build -- Morton domains + LET exchange --
+// runs one process per GPU: wgpu_n_body_amd/sharded.py.)
 #include <atomic>
 #include <condition_variable>
 #include <memory>
@@ -65,6 +74,7 @@ struct NaiveGroup::Rank {
     NaiveSim *naive = nullptr;
     int device = 0;
     hipEvent_t done[2] = {nullptr, nullptr};
+    hipEvent_t pushed[2] = {nullptr, nullptr};  // Barnes-Hut: "my slices are in every peer's arrays"
     std::thread th;
     int rc = NB_OK;
     std::string err;
@@ -96,12 +106,14 @@ NaiveGroup::~NaiveGroup() {
         if (r->sim) (void)r->sim->wait();
         for (hipEvent_t e : r->done)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : r->pushed)
+            if (e) (void)hipEventDestroy(e);
         r->sim.reset();
     }
 }
 
-int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_particle *particles,
-                       const int *device_ids, int n_devices) {
+int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
+                       const nb_particle *particles, const int *device_ids, int n_devices) {
     if (!device_ids || n_devices < 1 || n_devices > kMaxPeers + 1) {
         set_error("nb_runner_create_multi: between 1 and %d devices", kMaxPeers + 1);
         return NB_ERR_INVALID;
@@ -117,6 +129,7 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
         return NB_ERR_ALLOC;
     }
     g->params_ = sp;
+    g->tree_ = add.kind == NB_TREE_SIM_PARAMS;
     const int world = n_devices;
     for (int r = 0; r < world; ++r) {
         if (device_ids[r] < 0 || device_ids[r] >= visible) {
@@ -129,11 +142,11 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
         pl.device_id = device_ids[r];
         pl.rank = r;
         pl.world = world;
-        const nb_add_params add{NB_NAIVE_SIM_PARAMS, 0.f};
         if (int rc = make_sim_impl(rk->sim, &sp, &add, &pl, particles, sp.particle_num)) return rc;
-        rk->naive = static_cast<NaiveSim *>(rk->sim.get());
+        rk->naive = g->tree_ ? nullptr : static_cast<NaiveSim *>(rk->sim.get());
         NB_HIP_TRY(hipSetDevice(rk->device));
         for (hipEvent_t &e : rk->done) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : rk->pushed) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         g->ranks_.push_back(std::move(rk));
     }
     // peer access between every pair of distinct devices, then hand every rank its peers' buffers
@@ -153,7 +166,7 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
             (void)hipGetLastError();
         }
     }
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < world && !g->tree_; ++r) {
         float4 *b0[kMaxPeers], *b1[kMaxPeers];
         int k = 0;
         for (int q = 0; q < world; ++q) {
@@ -199,16 +212,67 @@ void NaiveGroup::worker(int r) {
             std::lock_guard<std::mutex> lk(sh_->mu);
             return sh_->failed;
         };
-        for (int s = 0; s < steps; ++s) {
+        auto wait_all = [&](hipEvent_t Rank::*arr_unused, bool pushed_ev, uint64_t idx) -> hipError_t {
+            (void)arr_unused;
+            hipError_t e = hipSuccess;
+            for (int q = 0; q < world && e == hipSuccess; ++q)
+                if (q != r)
+                    e = hipStreamWaitEvent(me.sim->stream, pushed_ev ? ranks_[q]->pushed[idx & 1] : ranks_[q]->done[idx & 1], 0);
+            return e;
+        };
+        for (int s = 0; s < steps && tree_; ++s) {
+            // Barnes-Hut, replicated tree: [peers' slices of step t-1 are in] build + walk my range
+            // [every rank has finished step t] copy my slices into every peer's arrays
+            const uint64_t t = step_ + (uint64_t)s;
+            sh_->bar->wait();  // every rank has recorded its "slices of step t-1 pushed"
+            if (!failed()) {
+                hipError_t e = t > 0 ? wait_all(nullptr, true, t - 1) : hipSuccess;
+                if (e != hipSuccess) {
+                    set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+                    fail(NB_ERR_HIP);
+                } else if (int rc = me.sim->encode()) {
+                    fail(rc);
+                } else if ((e = hipEventRecord(me.done[t & 1], me.sim->stream)) != hipSuccess) {
+                    set_error("hipEventRecord failed: %s", hipGetErrorString(e));
+                    fail(NB_ERR_HIP);
+                }
+            }
+            sh_->bar->wait();  // every rank has recorded its "step t finished"
+            if (!failed()) {
+                hipError_t e = wait_all(nullptr, false, t);
+                for (int k = 0; k < 3 && e == hipSuccess; ++k) {  // positions/masses, velocities, accelerations
+                    void *mine = nullptr;
+                    size_t off = 0, len = 0, total = 0;
+                    if (int rc = me.sim->exchange_region(k, &mine, &off, &len, &total)) {
+                        fail(rc);
+                        break;
+                    }
+                    for (int q = 0; q < world && e == hipSuccess; ++q) {
+                        if (q == r) continue;
+                        void *theirs = nullptr;
+                        size_t o2 = 0, l2 = 0, t2 = 0;
+                        if (int rc = ranks_[q]->sim->exchange_region(k, &theirs, &o2, &l2, &t2)) {
+                            fail(rc);
+                            break;
+                        }
+                        e = hipMemcpyPeerAsync(static_cast<char *>(theirs) + off, ranks_[q]->device,
+                                               static_cast<char *>(mine) + off, me.device, len, me.sim->stream);
+                    }
+                }
+                if (e == hipSuccess) e = hipEventRecord(me.pushed[t & 1], me.sim->stream);
+                if (e != hipSuccess) {
+                    set_error("slice push failed: %s", hipGetErrorString(e));
+                    fail(NB_ERR_HIP);
+                }
+            }
+        }
+        for (int s = 0; s < steps && !tree_; ++s) {
             const uint64_t t = step_ + (uint64_t)s;  // absolute step index (same on every rank)
             if (!failed())
                 if (int rc = me.sim->encode_phase(0)) fail(rc);  // own j tiles: nothing to wait for
             sh_->bar->wait();  // every rank has recorded its "step t-1 finished"
             if (!failed()) {
-                hipError_t e = hipSuccess;
-                if (t > 0)
-                    for (int q = 0; q < world && e == hipSuccess; ++q)
-                        if (q != r) e = hipStreamWaitEvent(me.sim->stream, ranks_[q]->done[(t - 1) & 1], 0);
+                hipError_t e = t > 0 ? wait_all(nullptr, false, t - 1) : hipSuccess;
                 if (e != hipSuccess) {
                     set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
                     fail(NB_ERR_HIP);
@@ -269,6 +333,7 @@ int NaiveGroup::read_particles(nb_particle *dst, size_t count) {
         set_error("read_particles: asked for %zu of %zu particles", count, n);
         return NB_ERR_INVALID;
     }
+    if (tree_) return ranks_[0]->sim->read_particles(dst, count);  // replicated: every rank holds every body
     std::vector<nb_particle> tmp(n), all(n);
     for (size_t r = 0; r < ranks_.size(); ++r) {
         SimBase &s = *ranks_[r]->sim;

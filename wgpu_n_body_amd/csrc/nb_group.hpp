@@ -1,4 +1,5 @@
-// nb_group.hpp -- the one-process multi-GPU all-pairs runner behind nb_runner_create_multi.
+// nb_group.hpp -- the one-process multi-GPU runner behind nb_runner_create_multi (all-pairs: peer
+// stores from the finish kernel; Barnes-Hut: replicated tree, partitioned walk, peer copies).
 #pragma once
 
 #include <memory>
@@ -13,8 +14,8 @@ class NaiveGroup {
    public:
     ~NaiveGroup();
     // bodies [r per, (r+1) per) on device_ids[r]; a device id may repeat (ranks sharing a GPU)
-    static int create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_particle *particles,
-                      const int *device_ids, int n_devices);
+    static int create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
+                      const nb_particle *particles, const int *device_ids, int n_devices);
     int step_n(int steps);  // enqueue on every rank, return when every rank has finished
     int read_particles(nb_particle *dst, size_t count);
     const nb_sim_params &params() const { return params_; }
@@ -31,6 +32,7 @@ class NaiveGroup {
     std::unique_ptr<Shared> sh_;
     nb_sim_params params_{};
     uint64_t step_ = 0;
+    bool tree_ = false;  // Barnes-Hut: replicated tree, partitioned walk, slices copied to the peers
 };
 
 }  // namespace nb

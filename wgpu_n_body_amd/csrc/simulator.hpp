@@ -195,7 +195,7 @@ class OfflineHeadless {
         }
         check(rc);
     }
-    // several GPUs of this process (nb_runner_create_multi; all-pairs): rank r owns a contiguous
+    // several GPUs of this process (nb_runner_create_multi): rank r owns a contiguous
     // body range on device_ids[r]
     OfflineHeadless(const SimParams &sp, const AddParams &ap, const InitFn &init, const std::vector<int> &device_ids) {
         detail::InitThunk thunk{&init, {}};
