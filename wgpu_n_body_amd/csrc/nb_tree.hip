@@ -964,7 +964,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
     // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
     // by-value copy of a kernel argument selected at run time lands in scratch memory)
-    const uint32_t n_roots = roots_dev ? roots_dev->count : roots_arg.count;
+    const uint32_t n_roots =  // (readfirstlane: see walk_cells_kernel)
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->count : roots_arg.count));
     __shared__ StackEntry s_stack[4][kWalkStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1006,7 +1007,8 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const uint64_t all = __ballot(valid);
     if (all) {  // the roots, pushed so that roots.id[0] is walked first
         for (uint32_t k = n_roots; k > 0u; --k) {
-            const uint32_t rid = roots_dev ? roots_dev->id[k - 1u] : roots_arg.id[k - 1u];
+            const uint32_t rid =
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->id[k - 1u] : roots_arg.id[k - 1u]));
             if (lane0) stack[sp] = StackEntry{rid, 1u, (uint32_t)all, (uint32_t)(all >> 32)};
             sp += 1;
         }
@@ -1113,6 +1115,9 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
 #ifndef NB_WALK_BLOCK_WAVES
 #define NB_WALK_BLOCK_WAVES 1
 #endif
+#ifndef NB_WALK_MIN_WAVES
+#define NB_WALK_MIN_WAVES 5  // waves per SIMD the register budget of the cells walk is held to
+#endif
 constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
 constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (7 KiB); see the batch-size rule in the loop
 constexpr uint32_t kCellReserve = 160;
@@ -1148,40 +1153,54 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 
 // One batch of the cells walk: the lane's cell (q = centre of gravity + mass, ssize2) against the G
 // bodies of the group.  vm: the bodies that have to test the cell (body b at bit 31 - b); returns
-// the bodies that open it (same format).  SELF: some lane of the batch holds the leaf of one of
-// the group's own bodies (tm = vm without that body: a leaf is never taken by its own body, SURVEY
-// A14) -- true for one batch of a walk, so the common path spends nothing on it.
-template <int G, bool SELF, bool COUNT>
-__device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssize2, uint32_t vm, uint32_t tm,
-                                                const float (&bx)[G], const float (&by)[G],
-                                                const float (&bz)[G], const float theta2, const float e,
-                                                float (&ax)[G], float (&ay)[G], float (&az)[G],
+// the bodies that open it (same format); a body whose bit is set and that accepts the cell takes it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two bodies of the group per packed-fp32 instruction (v_pk_add/mul/fma_f32: two IEEE binary32
+// operations per lane and issue slot, each rounded as the scalar instruction rounds it, so every
+// bit is what the one-body-at-a-time form computes): bodies 2k and 2k+1 in the halves of bx[k].
+template <int G, bool COUNT>
+__device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssize2, uint32_t vm,
+                                                const v2f (&bx)[G / 2], const v2f (&by)[G / 2],
+                                                const v2f (&bz)[G / 2], const float theta2, const float e,
+                                                v2f (&ax)[G / 2], v2f (&ay)[G / 2], v2f (&az)[G / 2],
                                                 unsigned long long &n_accepts) {
     uint32_t om = 0u;  // body b ends up at bit G - 1 - b
 #pragma unroll
-    for (int b = 0; b < G; ++b) {
-        const float dx = q.x - bx[b], dy = q.y - by[b], dz = q.z - bz[b];
-        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    for (int k = 0; k < G / 2; ++k) {
+        const v2f dx = v2f{q.x, q.x} - bx[k], dy = v2f{q.y, q.y} - by[k], dz = v2f{q.z, q.z} - bz[k];
+        const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
         // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
         // negative size makes it always true.  Lane sets as 64-bit scalar masks.
-        const uint64_t far = __ballot(ssize2 < theta2 * r2);
-        const uint64_t visit = shl1_carry_out(vm);
-        const uint64_t take = far & (SELF ? shl1_carry_out(tm) : visit);
-        const uint64_t open = visit & ~far;
-        const float dist = __builtin_amdgcn_sqrtf(r2);
-        float w = q.w * __builtin_amdgcn_rcpf(__builtin_fmaf(e, dist, r2 * r2));
-        w = __builtin_amdgcn_inverse_ballot_w64(take) ? w : 0.0f;  // predicated, not branched
-        ax[b] = __builtin_fmaf(w, dx, ax[b]);
-        ay[b] = __builtin_fmaf(w, dy, ay[b]);
-        az[b] = __builtin_fmaf(w, dz, az[b]);
-        om = shl1_carry_in(om, open);
-        if (COUNT) n_accepts += __builtin_amdgcn_inverse_ballot_w64(take) ? 1ull : 0ull;
+        const v2f t2 = v2f{theta2, theta2} * r2;
+        const uint64_t far0 = __ballot(ssize2 < t2.x), far1 = __ballot(ssize2 < t2.y);
+        const uint64_t visit0 = shl1_carry_out(vm), visit1 = shl1_carry_out(vm);
+        const uint64_t take0 = far0 & visit0, take1 = far1 & visit1;
+        const uint64_t open0 = visit0 & ~far0, open1 = visit1 & ~far1;
+        v2f dist;
+        dist.x = __builtin_amdgcn_sqrtf(r2.x);
+        dist.y = __builtin_amdgcn_sqrtf(r2.y);
+        const v2f den = __builtin_elementwise_fma(v2f{e, e}, dist, r2 * r2);
+        v2f rc;
+        rc.x = __builtin_amdgcn_rcpf(den.x);
+        rc.y = __builtin_amdgcn_rcpf(den.y);
+        v2f w = v2f{q.w, q.w} * rc;
+        w.x = __builtin_amdgcn_inverse_ballot_w64(take0) ? w.x : 0.0f;  // predicated, not branched
+        w.y = __builtin_amdgcn_inverse_ballot_w64(take1) ? w.y : 0.0f;
+        ax[k] = __builtin_elementwise_fma(w, dx, ax[k]);
+        ay[k] = __builtin_elementwise_fma(w, dy, ay[k]);
+        az[k] = __builtin_elementwise_fma(w, dz, az[k]);
+        om = shl1_carry_in(om, open0);
+        om = shl1_carry_in(om, open1);
+        if (COUNT)
+            n_accepts += (__builtin_amdgcn_inverse_ballot_w64(take0) ? 1ull : 0ull) +
+                         (__builtin_amdgcn_inverse_ballot_w64(take1) ? 1ull : 0ull);
 #ifdef NB_DIAG_EXTRA_VALU   // sensitivity probe: two more transcendentals and three fma per pair
-        {
-            const float t = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(r2 + 1.0f));
-            float u = __builtin_fmaf(t, dx, dy);
-            u = __builtin_fmaf(t, u, dz);
-            u = __builtin_fmaf(t, u, dx);
+        for (int h = 0; h < 2; ++h) {
+            const float t = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((h ? r2.y : r2.x) + 1.0f));
+            float u = __builtin_fmaf(t, dx.x, dy.x);
+            u = __builtin_fmaf(t, u, dz.x);
+            u = __builtin_fmaf(t, u, dx.y);
             asm volatile("" ::"v"(u));
         }
 #endif
@@ -1194,7 +1213,7 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
 // and gets bit for bit what the one-launch step (PART 0) computes.
 template <int G, bool COUNT, int PART>
 // (G <= 8: at most 96 VGPRs, so that five waves fit a SIMD -- the compiler lands on 90..100 by itself)
-__global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAVES)) void walk_cells_kernel(
+__global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAVES : NB_WALK_WAVES)) void walk_cells_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots_arg, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
@@ -1203,7 +1222,11 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
     // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
     // by-value copy of a kernel argument selected at run time lands in scratch memory)
-    const uint32_t n_roots = roots_dev ? roots_dev->count : roots_arg.count;
+    // (readfirstlane: the select between a kernel-argument field and device memory is a load
+    // through a flat pointer, which the compiler takes for lane-dependent -- and with it the stack
+    // pointer and the whole loop control, which then live in VGPRs under exec masks)
+    const uint32_t n_roots =
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->count : roots_arg.count));
     __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1223,21 +1246,21 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
         yi = drift(p.y, kick(v.y, a.y, dt), dt);
         zi = drift(p.z, kick(v.z, a.z, dt), dt);
     }
-    float bx[G], by[G], bz[G];  // the group's evaluation points, wave-uniform (SGPRs)
+    v2f bx[G / 2], by[G / 2], bz[G / 2];  // the group's evaluation points, wave-uniform (SGPR pairs)
 #pragma unroll
     for (int b = 0; b < G; ++b) {
-        bx[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xi), b));
-        by[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(yi), b));
-        bz[b] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(zi), b));
+        bx[b / 2][b % 2] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(xi), b));
+        by[b / 2][b % 2] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(yi), b));
+        bz[b / 2][b % 2] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(zi), b));
     }
     // bounding box of the group's evaluation points (for the all-open shortcut below)
-    float blx = bx[0], bly = by[0], blz = bz[0], bhx = bx[0], bhy = by[0], bhz = bz[0];
+    float blx = bx[0].x, bly = by[0].x, blz = bz[0].x, bhx = blx, bhy = bly, bhz = blz;
 #pragma unroll
     for (int b = 1; b < G; ++b) {
         if ((uint32_t)b < nvalid) {
-            blx = fminf(blx, bx[b]); bhx = fmaxf(bhx, bx[b]);
-            bly = fminf(bly, by[b]); bhy = fmaxf(bhy, by[b]);
-            blz = fminf(blz, bz[b]); bhz = fmaxf(bhz, bz[b]);
+            blx = fminf(blx, bx[b / 2][b % 2]); bhx = fmaxf(bhx, bx[b / 2][b % 2]);
+            bly = fminf(bly, by[b / 2][b % 2]); bhy = fmaxf(bhy, by[b / 2][b % 2]);
+            blz = fminf(blz, bz[b / 2][b % 2]); bhz = fmaxf(bhz, bz[b / 2][b % 2]);
         }
     }
     // (wave-uniform values computed by the vector unit: move them to SGPRs)
@@ -1248,7 +1271,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
         publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
                                                      fmaxf(fabsf(blz), fabsf(bhz))));
     const float theta2 = theta * theta;
-    const uint32_t root0 = roots_dev ? roots_dev->id[0] : roots_arg.id[0];  // a record every idle lane may read
+    const uint32_t root0 =  // a record every idle lane may read
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->id[0] : roots_arg.id[0]));
     const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
     CellEnt *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
@@ -1271,10 +1295,11 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
         if (lane < sp)
             stack[lane] = CellEnt{roots_dev ? roots_dev->id[r_lo + lane] : roots_arg.id[r_lo + lane], group_mask};
         __builtin_amdgcn_wave_barrier();
-        float ax[G], ay[G], az[G];
+        v2f ax[G / 2], ay[G / 2], az[G / 2];
 #pragma unroll
-        for (int b = 0; b < G; ++b) ax[b] = ay[b] = az[b] = 0.f;
+        for (int k = 0; k < G / 2; ++k) ax[k] = ay[k] = az[k] = v2f{0.f, 0.f};
 
+        bool overflowed = false;
         while (sp > 0u) {
             // Batch size: up to 64 cells, fewer when their children (at most 8 each: 7 net per
             // popped cell) would eat into the reserve.  Popping from the top keeps the walk
@@ -1286,7 +1311,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
             const uint32_t lim = free_slots > kCellReserve ? (free_slots - kCellReserve) / 7u : 0u;
             const uint32_t c = max(1u, min(min(64u, sp), lim));
             if (free_slots < 7u) {
-                if (lane == 0u) atomicAdd(&status[3], 1u);
+                overflowed = true;
                 break;
             }
             sp -= c;
@@ -1316,7 +1341,6 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
 #endif
             // a leaf is never taken by its own body; cells carry self_pos = ~0, no body of the group
             const uint32_t sb = r.self_pos - i0;
-            uint32_t om;
             // The top of the tree: a batch of a few big cells (the root, its children; also the
             // roots of imported trees) that EVERY body of the group opens.  One test per lane against
             // the group's bounding box decides it without touching the bodies: with the largest
@@ -1331,13 +1355,13 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
                 const float r2max = __builtin_fmaf(dzm, dzm, __builtin_fmaf(dym, dym, dxm * dxm));
                 all_open = __ballot(active && (r.ssize2 < theta2 * r2max)) == 0ull;
             }
-            if (all_open) {
-                om = vm;
-            } else if (__ballot(sb < (uint32_t)G) == 0ull) {
-                om = cells_batch<G, false, COUNT>(r.cogm, r.ssize2, vm, vm, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
-            } else {
-                const uint32_t tm = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
-                om = cells_batch<G, true, COUNT>(r.cogm, r.ssize2, vm, tm, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
+            // (the leaf of one of the group's own bodies: that body's bit leaves the lane's set -- a
+            // leaf is never opened, so all the bit could do is take the leaf -- instead of a second
+            // evaluation path with "take" masks of its own)
+            uint32_t om = vm;
+            if (!all_open) {
+                const uint32_t em = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
+                om = cells_batch<G, COUNT>(r.cogm, r.ssize2, em, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
             }
             if (COUNT) {
                 n_visits += (unsigned long long)__popc(vm);
@@ -1346,7 +1370,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
                 n_leaves += (uint32_t)__popcll(__ballot(active && r.count == 0u));
             }
 #ifdef NB_DIAG_PHASES
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(om), "v"(ax[0]), "v"(ay[G - 1]));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(om), "v"(ax[0].x), "v"(ay[G / 2 - 1].y));
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
             // push the children of the opened cells: lane l writes its cnt entries at
@@ -1378,6 +1402,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
             ph[3] += t4 - t3;
 #endif
         }
+        if (overflowed && lane == 0u) atomicAdd(&status[3], 1u);  // (reported outside the loop: see sp above)
         // The G sums of this root set, in a fixed order, through the (now empty) stack's LDS: every
         // lane stores its G partial sums of one component; lane l then adds the partial sums of the
         // lanes [p G, p G + G) of body b, with b = l / L, p = l % L, L = 64 / G lanes per body; the L
@@ -1391,7 +1416,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? 5 : NB_WALK_WAV
             for (int comp = 0; comp < 3; ++comp) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int b = 0; b < G; ++b) red[b * 64 + (int)lane] = comp == 0 ? ax[b] : comp == 1 ? ay[b] : az[b];
+                for (int b = 0; b < G; ++b)
+                    red[b * 64 + (int)lane] = comp == 0 ? ax[b / 2][b % 2] : comp == 1 ? ay[b / 2][b % 2] : az[b / 2][b % 2];
                 __builtin_amdgcn_wave_barrier();
                 float sacc = 0.f;
 #pragma unroll
