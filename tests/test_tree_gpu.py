@@ -427,3 +427,25 @@ def test_tree_step_in_two_phases(gpu):
     assert np.array_equal(a.dest_particle_slice(), b.dest_particle_slice())
     a.destroy()
     b.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,init", [(20000, "uniform"), (20000, "disc"), (100000, "uniform"), (100000, "disc"),
+                                    (600000, "uniform"), (600000, "disc")])
+def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
+    """Above 16,384 bodies the radix sort covers only the high key bits (3 passes of 8 bits at 20,000
+    and 100,000 bodies, 4 at 600,000) and fixes the runs that tie there up afterwards;
+    `tree_sort_mode` 0 runs eight passes over the whole key instead.  Both must give the same stable
+    order by key (which the oracle pins at <= 20,000 bodies above and at 2^20 / 4 M / 8 M bodies in
+    test_full_size_gpu.py): body order, tree and new state bit for bit the same, after 2 steps (the
+    second sorts a state that is already in sorted order; the disc has thousands of runs)."""
+    nb = gpu
+    sp = nb.SimParams(particle_num=n)
+    state = nb.as_floats(getattr(nb.inits, init + "_init")(sp, seed=n % 97))
+    a = run_tree(nb, state, 0.75, steps=2, count=False)
+    b = run_tree(nb, state, 0.75, steps=2, count=False, tuning={"tree_sort_mode": 0})
+    assert not a["status"].any() and not b["status"].any()
+    assert np.array_equal(a["order"], b["order"])
+    assert np.array_equal(np.sort(a["order"]), np.arange(n, dtype=np.uint32))
+    assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
+    assert np.array_equal(bits(a["dst"]), bits(b["dst"]))

@@ -130,7 +130,7 @@ static void walk_group(uint32_t lo, int G, float theta2, Stats *st) {
 // LIFO stack of (cell, G-bit visit mask); a batch pops up to 64 cells, every lane tests its cell
 // against each of the G bodies, the children of opened cells are pushed (siblings contiguous).
 typedef struct { uint32_t id; uint32_t mask; } CEnt;
-typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any; } CStats;
+typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any, tpairs, thalves, lo_only, hi_only; } CStats;
 static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, CStats *st) {
     static _Thread_local CEnt stack[1 << 16];
     int sp = 0, hw = 0;
@@ -146,6 +146,13 @@ static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, C
             const Rec *r = &rec[cur[l].id];
             uint32_t open = 0;
             any |= cur[l].mask;
+            if (G == 8) {   // touched body pairs / halves of the mask (packing granularities)
+                const uint32_t m = cur[l].mask;
+                st->tpairs += ((m & 3) != 0) + ((m & 12) != 0) + ((m & 48) != 0) + ((m & 192) != 0);
+                st->thalves += ((m & 15) != 0) + ((m & 240) != 0);
+                if ((m & 240) == 0) st->lo_only += 1;
+                if ((m & 15) == 0) st->hi_only += 1;
+            }
             for (int b = 0; b < nb; ++b) {
                 if (!((cur[l].mask >> b) & 1)) continue;
                 const f4 p = kp[lo + b].p;
@@ -241,12 +248,16 @@ int main(int argc, char **argv) {
             {
                 tot.batches += st.batches; tot.cells += st.cells; tot.pairs += st.pairs; tot.visits += st.visits;
                 tot.hw += st.hw; tot.pairs_any += st.pairs_any; if (st.maxhw > tot.maxhw) tot.maxhw = st.maxhw;
+                tot.tpairs += st.tpairs; tot.thalves += st.thalves; tot.lo_only += st.lo_only; tot.hi_only += st.hi_only;
             }
         }
         const double ngroups = (double)((n64 + stride - 1) / stride) * (64 / G);
         printf(" G %2d: batches/group %.1f  cells/group %.1f  fill %.3f  pair-instr per 64 bodies %.0f  util %.3f  (skipping bodies absent from a batch: %.0f, util %.3f)  stack high water mean %.0f max %.0f\n",
                G, tot.batches / ngroups, tot.cells / ngroups, tot.cells / (tot.batches * 64), tot.pairs / 64 / ngroups * (64 / G),
                tot.visits / tot.pairs, tot.pairs_any / 64 / ngroups * (64 / G), tot.visits / tot.pairs_any, tot.hw / ngroups, tot.maxhw);
+        if (G == 8)
+            printf("       per popped cell: bodies that visit it %.2f of 8; touched pairs %.2f of 4; touched halves %.2f of 2; lo-half only %.1f %% hi-half only %.1f %%\n",
+                   tot.visits / tot.cells, tot.tpairs / tot.cells, tot.thalves / tot.cells, 100 * tot.lo_only / tot.cells, 100 * tot.hi_only / tot.cells);
     }
 
     printf("\nscheme C with cell-aligned groups (a group never straddles a cell of > 8 bodies), G = 8 slots\n");

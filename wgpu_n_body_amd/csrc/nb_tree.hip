@@ -51,6 +51,7 @@ namespace {
 constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
+constexpr uint32_t kSortBits = 8, kSortMaxBins = 1u << kSortBits;  // digit width (the kernels take 7..9)
 constexpr uint32_t kSortInlineScanBlocks = 16;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
 // wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
 // most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
@@ -106,11 +107,13 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
                                                               uint64_t *__restrict__ keys,
                                                               uint32_t *__restrict__ idx,
                                                               uint32_t *__restrict__ hist, uint32_t nblocks,
-                                                              uint32_t items) {
-    // (items = kSortItems: a workgroup is a sort tile and leaves its first-digit histogram; the
-    // counting sort of small problems needs no histogram and takes items = 1: more, shorter workgroups)
-    __shared__ uint32_t s_hist[256];
-    s_hist[threadIdx.x] = 0;
+                                                              uint32_t items, uint32_t hist_shift,
+                                                              uint32_t hist_bins) {
+    // (items = kSortItems: a workgroup is a sort tile and leaves the tile's histogram of the digit the
+    // FIRST radix pass sorts by -- hist_bins values at bit hist_shift; the counting sort of small
+    // problems needs no histogram and takes items = 1: more, shorter workgroups)
+    __shared__ uint32_t s_hist[kSortMaxBins];
+    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += kSortThreads) s_hist[b] = 0;
     __syncthreads();
     uint32_t bmax = 0;
     for (uint32_t k = 0; k < n_src; ++k) bmax = max(bmax, bound_src[k]);
@@ -136,13 +139,14 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
         }
         keys[i] = key;
         idx[i] = i;
-        atomicAdd(&s_hist[(uint32_t)key & 255u], 1u);
+        if (hist) atomicAdd(&s_hist[(uint32_t)(key >> hist_shift) & (hist_bins - 1u)], 1u);
     }
     __syncthreads();
-    if (hist) hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];  // bin-major
+    if (hist)
+        for (uint32_t b = threadIdx.x; b < hist_bins; b += kSortThreads) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
 }
 
-// ---- 3. radix sort (LSD, 8-bit digits, pairs) ---------------------------------------------------
+// ---- 3. radix sort (LSD, digits of W bits, pairs) ------------------------------------------------
 // A block owns a tile of kSortTile elements; wave w owns the contiguous sub-range
 // [w*64*ITEMS, (w+1)*64*ITEMS) of it, read in ITEMS chunks of 64 -- so "wave, chunk, lane" order
 // IS the input order, which is what makes the per-wave ranking below stable.
@@ -150,20 +154,20 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
 // per element where it lands, was measured and dropped: 47 instead of 12 us per scatter at 2^20
 // bodies, 10.8 instead of 5 + 5 at 8,192 -- profiles/r02_sort_experiments.txt.)
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
-    const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t *__restrict__ hist,
+    const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins, uint32_t *__restrict__ hist,
     uint32_t nblocks) {
-    __shared__ uint32_t s_hist[256];
-    s_hist[threadIdx.x] = 0;
+    __shared__ uint32_t s_hist[kSortMaxBins];
+    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += kSortThreads) s_hist[b] = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t base = blockIdx.x * kSortTile + wave * (64 * kSortItems);
 #pragma unroll
     for (uint32_t c = 0; c < kSortItems; ++c) {
         const uint32_t i = base + c * 64 + lane;
-        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (bins - 1u)], 1u);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = s_hist[threadIdx.x];  // bin-major
+    for (uint32_t b = threadIdx.x; b < bins; b += kSortThreads) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
 }
 
 // One workgroup per bin: exclusive scan of that bin's per-block counts; the bin total goes to
@@ -197,44 +201,65 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t *__restrict__ hi
     if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
 }
 
+// exclusive scan over the workgroup of one value per thread (256 threads)
+__device__ __forceinline__ uint32_t sort_scan_256(uint32_t v, uint32_t *s_w) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if ((int)lane >= o) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+    __syncthreads();
+    return off + x - v;
+}
+
 // SCAN_INLINE (few tiles: the launch-bound small problems): `hist` holds the raw per-tile counts
-// and every block sums its digit rows itself -- thread d adds up row d -- which saves the
-// bin_scan launch of the pass.
-template <bool SCAN_INLINE>
+// and every block sums its digit rows itself -- thread t adds up its rows -- which saves the
+// bin_scan launch of the pass.  Thread t looks after the digits [t PER, (t + 1) PER).
+template <int W, bool SCAN_INLINE>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals, uint32_t nblocks) {
-    __shared__ uint32_t s_cnt[4][256];  // per-wave running digit counts -> exclusive wave offsets
-    __shared__ uint32_t s_base[256];    // global start of each digit + this block's offset in it
+    constexpr uint32_t NB = 1u << W, PER = (NB + kSortThreads - 1u) / kSortThreads;
+    __shared__ uint32_t s_cnt[4][NB];  // per-wave running digit counts -> exclusive wave offsets
+    __shared__ uint32_t s_base[NB];    // global start of each digit + this block's offset in it
+    __shared__ uint32_t s_tile[NB], s_w[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
-    {   // exclusive scan of the 256 digit totals (tiny; every block redoes it)
-        uint32_t t, mine;  // digit total over all tiles; the tiles before this one
-        if (SCAN_INLINE) {
-            const uint32_t *row = hist + (size_t)threadIdx.x * nblocks;
-            t = 0u;
-            mine = 0u;
-            for (uint32_t b = 0; b < nblocks; ++b) {
-                const uint32_t v = row[b];
-                mine += b < blockIdx.x ? v : 0u;
-                t += v;
+    const uint32_t b0 = threadIdx.x * PER;  // my digits: b0 .. b0 + PER - 1 (none if b0 >= NB)
+    for (uint32_t w = 0; w < 4; ++w)
+        for (uint32_t b = threadIdx.x; b < NB; b += kSortThreads) s_cnt[w][b] = 0;
+    {   // exclusive scan of the digit totals (tiny; every block redoes it)
+        uint32_t t[PER], mine[PER], sum = 0;  // digit total over all tiles; the tiles before this one
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const uint32_t d = b0 + q;
+            t[q] = mine[q] = 0u;
+            if (d < NB) {
+                if (SCAN_INLINE) {
+                    const uint32_t *row = hist + (size_t)d * nblocks;
+                    for (uint32_t b = 0; b < nblocks; ++b) {
+                        const uint32_t v = row[b];
+                        mine[q] += b < blockIdx.x ? v : 0u;
+                        t[q] += v;
+                    }
+                } else {
+                    t[q] = totals[d];
+                    mine[q] = hist[d * nblocks + blockIdx.x];
+                }
             }
-        } else {
-            t = totals[threadIdx.x];
-            mine = hist[threadIdx.x * nblocks + blockIdx.x];
+            sum += t[q];
         }
-        uint32_t x = t;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
+        uint32_t run = sort_scan_256(sum, s_w);
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            if (b0 + q < NB) s_base[b0 + q] = run + mine[q];
+            run += t[q];
         }
-        __shared__ uint32_t s_w[4];
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
-        s_base[threadIdx.x] = off + x - t + mine;
     }
     __syncthreads();
 
@@ -248,11 +273,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const bool valid = i < n;
         key[c] = valid ? keys_in[i] : ~0ull;
         val[c] = valid ? vals_in[i] : 0u;
-        const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-        // lanes holding the same digit (ballot match over the 8 digit bits)
+        const uint32_t d = (uint32_t)(key[c] >> shift) & (NB - 1u);
+        // lanes holding the same digit (ballot match over the W digit bits)
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < W; ++b) {
             const uint64_t bal = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
@@ -264,29 +289,29 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         local[c] = before + rank;
     }
     __syncthreads();
-    uint32_t tile_count;
-    {   // per digit: exclusive prefix over the 4 waves, and the digit's count in this tile
-        uint32_t o = 0;
-        for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t t = s_cnt[w][threadIdx.x];
-            s_cnt[w][threadIdx.x] = o;
-            o += t;
+    {   // per digit: exclusive prefix over the 4 waves and the digit's count in this tile; then the
+        // exclusive scan of the tile's digit counts: where each digit's run starts inside the tile
+        uint32_t cnt[PER], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            cnt[q] = 0;
+            if (b0 + q < NB) {
+                uint32_t o = 0;
+                for (uint32_t w = 0; w < 4; ++w) {
+                    const uint32_t t = s_cnt[w][b0 + q];
+                    s_cnt[w][b0 + q] = o;
+                    o += t;
+                }
+                cnt[q] = o;
+            }
+            sum += cnt[q];
         }
-        tile_count = o;
-    }
-    // exclusive scan of the tile's digit counts: where each digit's run starts inside the tile
-    __shared__ uint32_t s_tile[256], s_w2[4];
-    {
-        uint32_t x = tile_count;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
+        uint32_t run = sort_scan_256(sum, s_w);
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            if (b0 + q < NB) s_tile[b0 + q] = run;
+            run += cnt[q];
         }
-        if (lane == 63) s_w2[wave] = x;
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t w = 0; w < wave; ++w) off += s_w2[w];
-        s_tile[threadIdx.x] = off + x - tile_count;
     }
     __syncthreads();
     // Stage the tile in LDS in digit order, then write it out with consecutive threads on
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     for (uint32_t c = 0; c < kSortItems; ++c) {
         const uint32_t i = base + c * 64 + lane;
         if (i < n) {
-            const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[c] >> shift) & (NB - 1u);
             const uint32_t pos = s_tile[d] + s_cnt[wave][d] + local[c];
             s_key[pos] = key[c];
             s_val[pos] = val[c];
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         const uint32_t j = c * kSortThreads + threadIdx.x;
         if (j < tile_n) {
             const uint64_t k = s_key[j];
-            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const uint32_t d = (uint32_t)(k >> shift) & (NB - 1u);
             const uint32_t dst = s_base[d] + (j - s_tile[d]);
             keys_out[dst] = k;
             vals_out[dst] = s_val[j];
@@ -393,31 +418,45 @@ __global__ __launch_bounds__(64 * kRankWaves) void rank_sort_kernel(const uint64
 // compares for a run of L.  The result is the stable full-key order, bit for bit the 8-pass sort's.
 constexpr uint32_t kRunWave = 64;
 
+constexpr uint32_t kRunMarkItems = 4;  // bodies per thread: one returning global atomic per 1,024 bodies and list
+
 __global__ __launch_bounds__(256) void runs_mark_kernel(const uint64_t *__restrict__ keys, uint32_t n,
                                                         uint32_t low_bits, uint32_t *__restrict__ short_list,
                                                         uint32_t *__restrict__ long_list,
                                                         uint32_t *__restrict__ counts) {
-    // (one global atomic per workgroup and list: tens of thousands of returning atomics on one word
-    // serialise at ~7 ns each)
+    // (returning atomics on one word serialise at ~7 ns each: one per workgroup and list, and a
+    // workgroup looks at 1,024 bodies -- at one per 256 bodies a clustered input, where most
+    // workgroups see a run, paid 30 us for them at 2^20 bodies; 4,096 bodies per workgroup are too
+    // few workgroups, 12 us)
     __shared__ uint32_t s_n[2], s_base[2];
     if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    int kind = -1;  // 0: first of a short run, 1: first of a long run
-    if (k + 1u < n) {
-        const uint64_t hi = keys[k] >> low_bits;
-        const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
-        if (first && (keys[k + 1u] >> low_bits) == hi)
-            // sorted by the high bits: if the body 64 places on still shares them, so do all in between
-            kind = (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) ? 1 : 0;
+    uint32_t kinds = 0, local[kRunMarkItems];  // 2 bits per item: 0 none, 1 first of a short run, 2 of a long run
+#pragma unroll
+    for (uint32_t c = 0; c < kRunMarkItems; ++c) {
+        const uint32_t k = (blockIdx.x * kRunMarkItems + c) * 256u + threadIdx.x;
+        uint32_t kind = 0;
+        if (k + 1u < n) {
+            const uint64_t hi = keys[k] >> low_bits;
+            const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
+            if (first && (keys[k + 1u] >> low_bits) == hi)
+                // sorted by the high bits: if the body 64 places on still shares them, so do all in between
+                kind = (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) ? 2u : 1u;
+        }
+        local[c] = kind ? atomicAdd(&s_n[kind - 1u], 1u) : 0u;
+        kinds |= kind << (2u * c);
     }
-    uint32_t local = 0;
-    if (kind >= 0) local = atomicAdd(&s_n[kind], 1u);
     __syncthreads();
     if (threadIdx.x < 2u && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_n[threadIdx.x]);
     __syncthreads();
-    if (kind == 0) short_list[s_base[0] + local] = k;
-    if (kind == 1) long_list[s_base[1] + local] = k;
+    if (kinds == 0u) return;
+#pragma unroll
+    for (uint32_t c = 0; c < kRunMarkItems; ++c) {
+        const uint32_t k = (blockIdx.x * kRunMarkItems + c) * 256u + threadIdx.x;
+        const uint32_t kind = (kinds >> (2u * c)) & 3u;
+        if (kind == 1u) short_list[s_base[0] + local[c]] = k;
+        if (kind == 2u) long_list[s_base[1] + local[c]] = k;
+    }
 }
 
 __global__ __launch_bounds__(256) void runs_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
@@ -1825,8 +1864,8 @@ class TreeSim final : public SimBase {
             if (int rc = alloc(&idx[b], sizeof(uint32_t) * nn)) return rc;
         }
         if (int rc = alloc(&d_aos, sizeof(nb_particle) * nn)) return rc;
-        if (int rc = alloc(&hist, sizeof(uint32_t) * 256 * (size_t)sort_blocks)) return rc;
-        if (int rc = alloc(&totals, sizeof(uint32_t) * 256)) return rc;
+        if (int rc = alloc(&hist, sizeof(uint32_t) * kSortMaxBins * (size_t)sort_blocks)) return rc;
+        if (int rc = alloc(&totals, sizeof(uint32_t) * kSortMaxBins)) return rc;
         if (int rc = alloc(&run_short, sizeof(uint32_t) * (nn / 2 + 2))) return rc;
         if (int rc = alloc(&run_long, sizeof(uint32_t) * (nn / kRunWave + 2))) return rc;
         if (int rc = alloc(&cpl, nn + 2)) return rc;
@@ -2254,12 +2293,28 @@ class TreeSim final : public SimBase {
         }
         bound_from_walk = false;
         const bool rank_sort = n <= kRankSortMax && sort_mode == 1;
+        // 3 / 3d: stable radix passes of kSortBits bits -- over all 63 key bits, or (sort_mode 1) only
+        // over the top `bits` bits, such that a cell of that level holds 1/64 body on average
+        // (2^bits >= 64 N), followed by the fix-up of the runs that tie there.
+        // (Digits of 9 bits -- 3 passes instead of 4 at 2^20 bodies -- were measured and dropped: the
+        // scatter of a pass costs 17 instead of 12 us and the fix-up sees 30x the runs,
+        // profiles/r02_sort_experiments.txt.)
+        uint32_t bits = 63;
+        if (sort_mode == 1) {
+            bits = 6;
+            while ((1ull << bits) < 64ull * n) ++bits;
+            bits = std::min(63u, std::max(21u, bits));
+        }
+        constexpr uint32_t W = kSortBits, bins = 1u << W;
+        const uint32_t passes = (bits + W - 1u) / W;
+        const uint32_t shift0 = 63u > passes * W ? 63u - passes * W : 0u;  // the passes cover bits shift0 .. 62
         if (rank_sort)
             hipLaunchKernelGGL(morton_kernel, dim3((n + kSortThreads - 1) / kSortThreads), dim3(kSortThreads), 0, stream,
-                               posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u);
-        else  // (the first-digit histogram it leaves is used when all eight passes run)
+                               posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u,
+                               0u, 1u);
+        else  // (with the tile histograms of the first pass's digit)
             hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
-                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, kSortItems);
+                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, kSortItems, shift0, bins);
         int kb = 0;
         if (rank_sort) {
             // 3c: the sorted position of every body counted in one launch
@@ -2267,39 +2322,30 @@ class TreeSim final : public SimBase {
                                keys[1], idx[1]);
             kb = 1;
         } else {
-            // 3 / 3d: stable radix passes of 8 bits -- all eight, or (sort_mode 1) only the top `hp` digits
-            // followed by the fix-up of the runs that tie there; hp such that a cell of that level
-            // holds 1/64 body on average (8 hp >= log2(64 N))
-            uint32_t hp = 8;
-            if (sort_mode == 1) {
-                uint32_t bits = 6;
-                while ((1ull << bits) < 64ull * n) ++bits;
-                hp = std::min(8u, std::max(3u, (bits + 7u) / 8u));
-            }
-            const uint32_t first = 8u - hp;  // passes first .. 7, digits at bit 8 * pass
-            for (uint32_t ps = first; ps < 8; ++ps) {
-                // (the lowest digit's tile histograms come with the keys when all eight passes run)
+            for (uint32_t ps = 0; ps < passes; ++ps) {
+                const uint32_t shift = shift0 + ps * W;
                 if (ps != 0u)
                     hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                       keys[kb], n, 8u * ps, hist, sort_blocks);
-                if (sort_blocks <= kSortInlineScanBlocks) {
-                    hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                       keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
+                                       keys[kb], n, shift, bins, hist, sort_blocks);
+                const bool inl = sort_blocks <= kSortInlineScanBlocks;
+                if (!inl) hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);
+                if (inl)
+                    hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, true>), dim3(sort_blocks), dim3(kSortThreads), 0,
+                                       stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
                                        sort_blocks);
-                } else {
-                    hipLaunchKernelGGL(bin_scan_kernel, dim3(256), b256, 0, stream, hist, sort_blocks, totals);
-                    hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                       keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, 8u * ps, hist, totals,
+                else
+                    hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, false>), dim3(sort_blocks), dim3(kSortThreads), 0,
+                                       stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
                                        sort_blocks);
-                }
                 kb ^= 1;
             }
-            if (first) {
+            if (shift0) {
                 uint32_t *run_counts = scalars + 12;  // zeroed by the previous step's cells_scan_kernel
-                hipLaunchKernelGGL(runs_mark_kernel, dim3(g256), b256, 0, stream, keys[kb], n, 8u * first, run_short,
+                hipLaunchKernelGGL(runs_mark_kernel, dim3((n + 256u * kRunMarkItems - 1u) / (256u * kRunMarkItems)), b256,
+                                   0, stream, keys[kb], n, shift0, run_short,
                                    run_long, run_counts);
                 hipLaunchKernelGGL(runs_sort_kernel, dim3(1024), b256, 0, stream, keys[kb], idx[kb], keys[kb ^ 1],
-                                   idx[kb ^ 1], n, 8u * first, run_short, run_long, run_counts);
+                                   idx[kb ^ 1], n, shift0, run_short, run_long, run_counts);
             }
         }
         uint64_t *skeys = keys[kb];
