@@ -50,9 +50,11 @@ namespace {
 
 constexpr int kLevels = 21;            // 3 x 21 = 63 key bits
 constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 guard)
-constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortTile = kSortThreads * kSortItems;
+// bodies per thread of a sort tile: 4 up to kSortSmallMax bodies (more, smaller workgroups: build
+// -13 us at 131,072 bodies, -5 at 524,288), 8 beyond (half the histogram rows: -14 us at 2^20, -40 at 2^21)
+constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortItemsSmall = 4, kSortSmallMax = 786432;
 constexpr uint32_t kSortBits = 8, kSortMaxBins = 1u << kSortBits;  // digit width (the kernels take 7..9)
-constexpr uint32_t kSortInlineScanBlocks = 16;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
+constexpr uint32_t kSortInlineScanBlocks = 32;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
 // wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
 // most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
 constexpr uint32_t kWalkStack = 192;
@@ -120,10 +122,19 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
     const float bound = fmaxf(1.0f, __uint_as_float(bmax));  // never below 1.0, tree.rs:427-433
     if (blockIdx.x == 0 && threadIdx.x == 0 && bound_src != bound_bits) *bound_bits = __float_as_uint(bound);
     const float root_w = bound * 2.0f;  // root width, tree.rs:465
-    for (uint32_t c = 0; c < items; ++c) {
+    // (the loads of a tile's bodies first, all in flight together: one body after the other the
+    // kernel waited out eight memory latencies per thread)
+    float4 pv[kSortItems];
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
         const uint32_t i = (blockIdx.x * items + c) * kSortThreads + threadIdx.x;
-        if (i >= n) break;
-        const float4 p = posm[i];
+        if (c < items && i < n) pv[c] = posm[i];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < kSortItems; ++c) {
+        const uint32_t i = (blockIdx.x * items + c) * kSortThreads + threadIdx.x;
+        if (c >= items || i >= n) break;
+        const float4 p = pv[c];
         float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
         uint64_t key = 0;
 #pragma unroll
@@ -147,12 +158,13 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
 }
 
 // ---- 3. radix sort (LSD, digits of W bits, pairs) ------------------------------------------------
-// A block owns a tile of kSortTile elements; wave w owns the contiguous sub-range
+// A block owns a tile of kSortThreads * ITEMS elements; wave w owns the contiguous sub-range
 // [w*64*ITEMS, (w+1)*64*ITEMS) of it, read in ITEMS chunks of 64 -- so "wave, chunk, lane" order
 // IS the input order, which is what makes the per-wave ranking below stable.
 // (Counting the tile histograms of digit p + 1 inside the scatter of pass p, with one global atomic
 // per element where it lands, was measured and dropped: 47 instead of 12 us per scatter at 2^20
 // bodies, 10.8 instead of 5 + 5 at 8,192 -- profiles/r02_sort_experiments.txt.)
+template <uint32_t ITEMS>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins, uint32_t *__restrict__ hist,
     uint32_t nblocks) {
@@ -160,9 +172,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
     for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += kSortThreads) s_hist[b] = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t base = blockIdx.x * kSortTile + wave * (64 * kSortItems);
+    const uint32_t base = blockIdx.x * (kSortThreads * ITEMS) + wave * (64 * ITEMS);
 #pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
+    for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t i = base + c * 64 + lane;
         if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (bins - 1u)], 1u);
     }
@@ -220,12 +232,12 @@ __device__ __forceinline__ uint32_t sort_scan_256(uint32_t v, uint32_t *s_w) {
 // SCAN_INLINE (few tiles: the launch-bound small problems): `hist` holds the raw per-tile counts
 // and every block sums its digit rows itself -- thread t adds up its rows -- which saves the
 // bin_scan launch of the pass.  Thread t looks after the digits [t PER, (t + 1) PER).
-template <int W, bool SCAN_INLINE>
+template <int W, uint32_t ITEMS, bool SCAN_INLINE>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals, uint32_t nblocks) {
-    constexpr uint32_t NB = 1u << W, PER = (NB + kSortThreads - 1u) / kSortThreads;
+    constexpr uint32_t NB = 1u << W, PER = (NB + kSortThreads - 1u) / kSortThreads, TILE = kSortThreads * ITEMS;
     __shared__ uint32_t s_cnt[4][NB];  // per-wave running digit counts -> exclusive wave offsets
     __shared__ uint32_t s_base[NB];    // global start of each digit + this block's offset in it
     __shared__ uint32_t s_tile[NB], s_w[4];
@@ -263,12 +275,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     __syncthreads();
 
-    const uint32_t base = blockIdx.x * kSortTile + wave * (64 * kSortItems);
+    const uint32_t base = blockIdx.x * TILE + wave * (64 * ITEMS);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint64_t key[kSortItems];
-    uint32_t val[kSortItems], local[kSortItems];
+    uint64_t key[ITEMS];
+    uint32_t val[ITEMS], local[ITEMS];
 #pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
+    for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t i = base + c * 64 + lane;
         const bool valid = i < n;
         key[c] = valid ? keys_in[i] : ~0ull;
@@ -317,10 +329,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     // Stage the tile in LDS in digit order, then write it out with consecutive threads on
     // consecutive elements: each digit's run lands in global memory as one contiguous, coalesced
     // stream instead of 64 scattered 8-byte stores per wave instruction.
-    __shared__ uint64_t s_key[kSortTile];
-    __shared__ uint32_t s_val[kSortTile];
+    __shared__ uint64_t s_key[TILE];
+    __shared__ uint32_t s_val[TILE];
 #pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
+    for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t i = base + c * 64 + lane;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[c] >> shift) & (NB - 1u);
@@ -330,9 +342,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         }
     }
     __syncthreads();
-    const uint32_t tile_n = min(kSortTile, n - blockIdx.x * kSortTile);
+    const uint32_t tile_n = min(TILE, n - blockIdx.x * TILE);
 #pragma unroll
-    for (uint32_t c = 0; c < kSortItems; ++c) {
+    for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t j = c * kSortThreads + threadIdx.x;
         if (j < tile_n) {
             const uint64_t k = s_key[j];
@@ -1850,7 +1862,8 @@ class TreeSim final : public SimBase {
         n_capacity = n;
         const size_t nn = n ? n : 1;
         node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
-        sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
+        sort_items = nn <= kSortSmallMax ? kSortItemsSmall : kSortItems;
+        sort_blocks = (uint32_t)((nn + kSortThreads * sort_items - 1) / (kSortThreads * sort_items));
         cell_tiles = (uint32_t)std::max({std::min<size_t>(nn, 131072) / 256, std::min<size_t>(nn, 524288) / 512, nn / kCellTile}) + 4;  // capacity
         const size_t npad = n_pad ? n_pad : 256;  // equal-sized slices for the all-gathers
         for (int b = 0; b < 2; ++b) {
@@ -2187,8 +2200,8 @@ class TreeSim final : public SimBase {
         hi = count;
         lo = 0;
         params.particle_num = count;
-        const size_t nn = n ? n : 1;
-        sort_blocks = (uint32_t)((nn + kSortTile - 1) / kSortTile);
+        const size_t nn = n ? n : 1;  // (the tile size stays the one the buffers were sized for)
+        sort_blocks = (uint32_t)((nn + kSortThreads * sort_items - 1) / (kSortThreads * sort_items));
     }
 
     // Imports of this step arrive in region 3 as (world - 1) segments of `stride` records, in rank
@@ -2314,7 +2327,7 @@ class TreeSim final : public SimBase {
                                0u, 1u);
         else  // (with the tile histograms of the first pass's digit)
             hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
-                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, kSortItems, shift0, bins);
+                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items, shift0, bins);
         int kb = 0;
         if (rank_sort) {
             // 3c: the sorted position of every body counted in one launch
@@ -2324,19 +2337,25 @@ class TreeSim final : public SimBase {
         } else {
             for (uint32_t ps = 0; ps < passes; ++ps) {
                 const uint32_t shift = shift0 + ps * W;
-                if (ps != 0u)
-                    hipLaunchKernelGGL(radix_hist_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream,
-                                       keys[kb], n, shift, bins, hist, sort_blocks);
                 const bool inl = sort_blocks <= kSortInlineScanBlocks;
-                if (!inl) hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);
-                if (inl)
-                    hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, true>), dim3(sort_blocks), dim3(kSortThreads), 0,
-                                       stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
-                                       sort_blocks);
-                else
-                    hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, false>), dim3(sort_blocks), dim3(kSortThreads), 0,
-                                       stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals,
-                                       sort_blocks);
+#define NB_PASS(ITEMS)                                                                                              \
+    do {                                                                                                            \
+        if (ps != 0u)                                                                                               \
+            hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(sort_blocks), dim3(kSortThreads), 0, stream,        \
+                               keys[kb], n, shift, bins, hist, sort_blocks);                                        \
+        if (inl) {                                                                                                  \
+            hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, ITEMS, true>), dim3(sort_blocks),                   \
+                               dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
+                               shift, hist, totals, sort_blocks);                                                   \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);            \
+            hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, ITEMS, false>), dim3(sort_blocks),                  \
+                               dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
+                               shift, hist, totals, sort_blocks);                                                   \
+        }                                                                                                           \
+    } while (0)
+                if (sort_items == kSortItemsSmall) NB_PASS(kSortItemsSmall); else NB_PASS(kSortItems);
+#undef NB_PASS
                 kb ^= 1;
             }
             if (shift0) {
@@ -2739,7 +2758,7 @@ class TreeSim final : public SimBase {
     NodeRec *rec = nullptr;  // per node: cogm + {first child id, child count} / leaf {sorted position, 0}
     Moments *mom_prefix = nullptr;
     unsigned long long *counters = nullptr;
-    uint32_t node_cap = 0, sort_blocks = 0;
+    uint32_t node_cap = 0, sort_blocks = 0, sort_items = kSortItems;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0;
