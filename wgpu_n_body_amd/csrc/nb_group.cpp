@@ -27,7 +27,7 @@
 // Barnes-Hut through the same runner is the replicated-tree scheme of SURVEY 8(e) step 1: every
 // rank holds the full state and builds the identical octree, walks only its range of the sorted
 // bodies, and its new position / velocity / acceleration slices are copied into every peer's
-// arrays (hipMemcpyPeerAsync on the rank's stream) once EVERY rank has finished the step -- a
+// arrays (one kernel on the rank's stream, stores through peer access) once EVERY rank has finished the step -- a
 // TreeSim's step reads and writes the same arrays, so the copies must not land while a peer still
 // reads them: two events per rank and step ("step finished", "slices pushed").  Bit for bit the
 // single TreeSim.  (The scheme that also shards the build -- Morton domains + LET exchange --
@@ -240,25 +240,19 @@ void NaiveGroup::worker(int r) {
             sh_->bar->wait();  // every rank has recorded its "step t finished"
             if (!failed()) {
                 hipError_t e = wait_all(nullptr, false, t);
-                for (int k = 0; k < 3 && e == hipSuccess; ++k) {  // positions/masses, velocities, accelerations
-                    void *mine = nullptr;
-                    size_t off = 0, len = 0, total = 0;
-                    if (int rc = me.sim->exchange_region(k, &mine, &off, &len, &total)) {
-                        fail(rc);
-                        break;
-                    }
-                    for (int q = 0; q < world && e == hipSuccess; ++q) {
-                        if (q == r) continue;
-                        void *theirs = nullptr;
+                // positions/masses, velocities, accelerations: one launch stores the slices into every peer
+                void *bases[3 * kMaxPeers];
+                int np = 0;
+                for (int q = 0; q < world && !failed(); ++q) {
+                    if (q == r) continue;
+                    for (int k = 0; k < 3; ++k) {
                         size_t o2 = 0, l2 = 0, t2 = 0;
-                        if (int rc = ranks_[q]->sim->exchange_region(k, &theirs, &o2, &l2, &t2)) {
-                            fail(rc);
-                            break;
-                        }
-                        e = hipMemcpyPeerAsync(static_cast<char *>(theirs) + off, ranks_[q]->device,
-                                               static_cast<char *>(mine) + off, me.device, len, me.sim->stream);
+                        if (int rc = ranks_[q]->sim->exchange_region(k, &bases[3 * np + k], &o2, &l2, &t2)) fail(rc);
                     }
+                    ++np;
                 }
+                if (!failed())
+                    if (int rc = me.sim->push_exchange(bases, np)) fail(rc);
                 if (e == hipSuccess) e = hipEventRecord(me.pushed[t & 1], me.sim->stream);
                 if (e != hipSuccess) {
                     set_error("slice push failed: %s", hipGetErrorString(e));

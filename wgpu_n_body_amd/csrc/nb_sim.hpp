@@ -32,6 +32,13 @@ class SimBase {
         set_error("this simulator has no exchange region");
         return NB_ERR_UNSUPPORTED;
     }
+    // one-process runner: store this rank's slice of every exchange region into the same place of
+    // every peer's arrays, in one launch on this simulator's stream (peer_bases[q * exchange_count()
+    // + k] = base of region k on peer q)
+    virtual int push_exchange(void *const *, int) {
+        set_error("this simulator has no peer push");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int let_set_imports(const uint32_t *, int) {
         set_error("let_set_imports: not a TreeSim");
         return NB_ERR_UNSUPPORTED;

@@ -543,6 +543,25 @@ __global__ void gather_va_kernel(const uint32_t *__restrict__ order, uint32_t n,
     acc_out[k] = acc_in[s];
 }
 
+// one-process multi-GPU runner (nb_group.cpp), replicated tree: the rank's new position / velocity /
+// acceleration slices stored into every peer's arrays through peer access, one launch
+struct PushDst {
+    float4 *p[3][kMaxPeers];
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void push_slices_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b,
+                                                          const float4 *__restrict__ c, PushDst dst, uint32_t first,
+                                                          uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4 va = a[first + i], vb = b[first + i], vc = c[first + i];
+    for (uint32_t q = 0; q < dst.n; ++q) {
+        dst.p[0][q][first + i] = va;
+        dst.p[1][q][first + i] = vb;
+        dst.p[2][q][first + i] = vc;
+    }
+}
+
 // ---- 5. cells from key prefixes -----------------------------------------------------------------
 // common prefix length in LEVELS of two keys (identical keys are clamped to kLevels-1 so that
 // every cell still has a depth <= kLevels; see the header about colliding keys)
@@ -2630,6 +2649,25 @@ class TreeSim final : public SimBase {
         if (off) *off = sizeof(float4) * (size_t)per_rank * (size_t)place.rank;
         if (len) *len = sizeof(float4) * (size_t)per_rank;
         if (total) *total = sizeof(float4) * (size_t)n_pad;
+        return NB_OK;
+    }
+
+    int push_exchange(void *const *peer_bases, int npeers) override {
+        if (let_world || npeers < 0 || npeers > kMaxPeers) {
+            set_error("push_exchange: replicated-tree placements only, at most %d peers", kMaxPeers);
+            return NB_ERR_INVALID;
+        }
+        const uint32_t first = per_rank * (uint32_t)place.rank;
+        const uint32_t count = first < n ? std::min(per_rank, n - first) : 0u;
+        if (npeers == 0 || count == 0u) return NB_OK;
+        if (int rc = bind_device()) return rc;
+        PushDst dst;
+        dst.n = (uint32_t)npeers;
+        for (int q = 0; q < npeers; ++q)
+            for (int k = 0; k < 3; ++k) dst.p[k][q] = static_cast<float4 *>(peer_bases[q * 3 + k]);
+        hipLaunchKernelGGL(push_slices_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, posm[cur], vel[cur],
+                           acc[cur], dst, first, count);
+        NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }
 
