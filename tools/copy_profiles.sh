@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copies what tools/collect_profiles.sh left under gpurun_out/ into the committed profiles/<tag>_* files.
+set -e
+cd "$(dirname "$0")/.."
+TAG=${1:-r02}
+O=gpurun_out/${TAG}final
+python tools/summarize_profile.py $TAG > /dev/null
+tail -1 $O/bench_n1.json > profiles/${TAG}_bench_n1.json
+cp "$(find gpurun_out/prof_tree_$TAG/trace -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_tree_kernel_stats.csv
+cp $O/tree_hbm_traffic.txt profiles/${TAG}_tree_hbm_traffic.txt
+cp $O/tree_walk_sq_counters.txt profiles/${TAG}_tree_walk_sq_counters.txt
+cp $O/criterion.txt profiles/${TAG}_criterion_sizes.txt
+cp $O/criterion_sizes.json profiles/${TAG}_criterion_sizes.json
+cp $O/tree_bench.txt profiles/${TAG}_tree_bench.txt
+grep '^{' $O/tree_bench_cpu_baseline.json | tail -1 > profiles/${TAG}_tree_bench_cpu_baseline.json
+: > profiles/${TAG}_step_timelines.txt
+for n in 8192 16384 131072 1048576; do
+  echo "=== tools/trace_tree.sh: one Barnes-Hut step at $n bodies (rocprofv3 --kernel-trace; start, gap to the previous kernel, duration) ===" >> profiles/${TAG}_step_timelines.txt
+  cat $O/trace_$n.txt >> profiles/${TAG}_step_timelines.txt
+done
+cp $O/headless_cli.txt profiles/${TAG}_headless_cli.txt
+grep -v "amdgpu.ids\|c10d\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/host_overhead.txt > profiles/${TAG}_host_overhead.txt
+git status --short profiles | head -20

@@ -857,7 +857,9 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t *keys, uint32
 // AOS = false (every step): only the 32-byte walk records.  AOS = true (nb_sim_read_tree, on
 // demand): also the reference's Octant fields -- cog, body count, the 8-entry children table
 // indexed by octant -- which cost two more dependent loads per child and 52 B of stores per node.
-template <bool AOS>
+constexpr uint32_t kFillEagerMax = 262144;  // bodies up to which fill_kernel fetches speculatively
+
+template <bool AOS, bool EAGER>
 __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint32_t n_cap,
                             const uint32_t *__restrict__ n_nodes_p,
                             const uint32_t *__restrict__ node_first,
@@ -886,41 +888,80 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     } else {
         const uint32_t d = dd;
         const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
+        // (Small problems are bound by this kernel's chain of dependent loads, not by its work: what
+        // depends only on k is fetched together and, EAGER, the first steps of the search and the
+        // eight candidate children likewise -- 6 loads deep instead of ~15: 11.6 -> 9.8 us at 16,384
+        // bodies.  At 2^20 bodies the kernel is bound by HBM traffic and the speculative loads cost
+        // 6 us: not EAGER there.)
+        const uint64_t key_k = keys[k];
+        const int left = cpl[k], right = cpl[k + 1];
+        const uint32_t slot_k = int_slot[k], leaf_k = leaf_id[k];
+        const Moments a = mom[k];
         // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
         uint32_t end = n;
         if (d != 0) {
-            const uint64_t limit = ((keys[k] >> shift) + 1ull) << shift;  // first key past the cell
+            const uint64_t limit = ((key_k >> shift) + 1ull) << shift;  // first key past the cell
             uint32_t lo_s = k + 1u, off = 1u;
-            while (k + off < n && keys[k + off] < limit) {
-                lo_s = k + off + 1u;
-                off <<= 1;
+            if (EAGER) {
+                uint64_t probe[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) probe[q] = keys[min(k + (1u << q), n - 1u)];  // k+1, k+2, k+4, k+8
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (off == (1u << q) && k + off < n && probe[q] < limit) {
+                        lo_s = k + off + 1u;
+                        off <<= 1;
+                    }
+                }
+            }
+            if (!EAGER || off == 16u) {
+                while (k + off < n && keys[k + off] < limit) {
+                    lo_s = k + off + 1u;
+                    off <<= 1;
+                }
             }
             end = lower_bound_key(keys, lo_s, min(k + off, n), limit);
         }
         if (AOS) bodies[id] = end - k;
         // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
         // (nodes of one depth are numbered in key order), starting with body k's own child
-        const int left = cpl[k], right = cpl[k + 1];
         uint32_t f;
         if ((int)d + 1 <= right) {  // body k also opens the cell one level down
-            const uint32_t slot = int_slot[k] + (d - (uint32_t)(left + 1) + 1u);
+            const uint32_t slot = slot_k + (d - (uint32_t)(left + 1) + 1u);
             f = slot < n_cap ? int_id[slot] : ~0u;
         } else {
-            f = leaf_id[k];
+            f = leaf_k;
         }
         const uint32_t lim = min(depth_base[d + 2], n_nodes);  // end of the depth-(d+1) ids
         uint32_t first = 0, cnt = 0;
-        for (uint32_t j = 0; j < 8u; ++j) {
-            const uint32_t cid = f + j;
-            if (f == ~0u || cid >= lim) break;
-            const uint32_t kc = node_first[cid];
-            if (j > 0 && kc >= end) break;
-            if (AOS) ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
-            if (cnt == 0u) first = cid;
-            ++cnt;
+        if (!EAGER) {
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t cid = f + j;
+                if (f == ~0u || cid >= lim) break;
+                const uint32_t kc = node_first[cid];
+                if (j > 0 && kc >= end) break;
+                if (AOS) ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+                if (cnt == 0u) first = cid;
+                ++cnt;
+            }
+        } else if (f != ~0u) {
+            uint32_t kc[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) kc[j] = node_first[min(f + j, n_nodes - 1u)];
+            bool more = true;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) {
+                const uint32_t cid = f + j;
+                more = more && cid < lim && (j == 0u || kc[j] < end);
+                if (more) {
+                    if (AOS) ch[(uint32_t)(keys[kc[j]] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+                    if (cnt == 0u) first = cid;
+                    ++cnt;
+                }
+            }
         }
         // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
-        const Moments a = mom[k], b2 = mom[end];
+        const Moments b2 = mom[end];
         const double m = b2.m - a.m;
         const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
                                 (float)((b2.z - a.z) / m), (float)m};
@@ -2407,9 +2448,14 @@ class TreeSim final : public SimBase {
         va_gathered = with_va;
         // 6: node contents
         const uint32_t gnodes = (node_cap + 255) / 256;
-        hipLaunchKernelGGL(fill_kernel<false>, dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
-                           node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                           mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
+        if (n <= kFillEagerMax)
+            hipLaunchKernelGGL((fill_kernel<false, true>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
+                               node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
+        else
+            hipLaunchKernelGGL((fill_kernel<false, false>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
+                               node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
         NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }
@@ -2562,7 +2608,7 @@ class TreeSim final : public SimBase {
             }
             // the Octant fields are produced on demand from the step's build arrays, which stay
             // intact until the next step (buffer cur^1 holds the sorted source the tree was built on)
-            hipLaunchKernelGGL(fill_kernel<true>, dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
+            hipLaunchKernelGGL((fill_kernel<true, false>), dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
                                n, node_cap, scalars + 1, node_first, node_depth, cpl, int_slot, leaf_id, int_id,
                                order, posm[cur ^ 1], mom_prefix, scalars + 16, scalars + 0, cogm, bodies, child,
                                rec);
