@@ -895,8 +895,13 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         // 6 us: not EAGER there.)
         const uint64_t key_k = keys[k];
         const int left = cpl[k], right = cpl[k + 1];
-        const uint32_t slot_k = int_slot[k], leaf_k = leaf_id[k];
-        const Moments a = mom[k];
+        // (only one of the two is needed: both are fetched ahead only where latency, not traffic, binds)
+        const bool opens_next = (int)d + 1 <= right;  // body k also opens the cell one level down
+        const uint32_t slot_k = (EAGER || opens_next) ? int_slot[k] : 0u;
+        const uint32_t leaf_k = (EAGER || !opens_next) ? leaf_id[k] : 0u;
+        Moments a{0, 0, 0, 0};
+        if (EAGER) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
+                                // fetched apart it has left the L2 by then: 185 -> 241 MB of HBM reads at 2^20)
         // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
         uint32_t end = n;
         if (d != 0) {
@@ -926,7 +931,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
         // (nodes of one depth are numbered in key order), starting with body k's own child
         uint32_t f;
-        if ((int)d + 1 <= right) {  // body k also opens the cell one level down
+        if (opens_next) {
             const uint32_t slot = slot_k + (d - (uint32_t)(left + 1) + 1u);
             f = slot < n_cap ? int_id[slot] : ~0u;
         } else {
@@ -961,6 +966,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             }
         }
         // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
+        if (!EAGER) a = mom[k];
         const Moments b2 = mom[end];
         const double m = b2.m - a.m;
         const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
