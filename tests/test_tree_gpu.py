@@ -104,7 +104,7 @@ def test_golden_fixtures(gpu, path):
 
 
 @pytest.mark.parametrize("kind,n,theta,g,dt", [
-    ("uniform", 2, 0.5, G, DT), ("uniform", 3, 0.5, G, DT), ("uniform", 63, 0.75, G, DT),
+    ("uniform", 1, 0.5, G, DT), ("uniform", 2, 0.5, G, DT), ("uniform", 3, 0.5, G, DT), ("uniform", 63, 0.75, G, DT),
     ("uniform", 65, 0.5, G, DT), ("spherical", 257, 0.3, G, DT), ("uniform", 4096, 0.5, G, DT),
     ("spherical", 5000, 0.75, G, DT), ("disc", 3000, 0.75, 0.00001, 0.0016),
     ("uniform", 20000, 1.0, G, DT)])

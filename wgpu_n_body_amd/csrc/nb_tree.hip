@@ -670,7 +670,9 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
             item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
             const uint64_t me = keys[k];
             const int left = k > 0 ? cpl_levels(keys[k - 1], me) : -1;
-            const int right = k + 1 < n ? cpl_levels(me, keys[k + 1]) : -1;
+            // (a lone body: the reference's root is always an internal octant -- the queue starts with the
+            // root partition whatever it holds, tree.rs:463-476 -- so the body's leaf sits at depth 1)
+            const int right = k + 1 < n ? cpl_levels(me, keys[k + 1]) : (n == 1u ? 0 : -1);
             if (k == 0) cpl[0] = -1;
             cpl[k + 1] = (int8_t)right;
             nint_sum += right > left ? (uint32_t)(right - left) : 0u;  // internal cells this body opens
