@@ -449,3 +449,24 @@ def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
     assert np.array_equal(np.sort(a["order"]), np.arange(n, dtype=np.uint32))
     assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
     assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
+
+
+@pytest.mark.gpu
+def test_single_body_and_empty_tree_sims(gpu, oracle):
+    """One body: pure kick-drift-kick with its old acceleration (no force: the only leaf is its own),
+    bit for bit the oracle -- velocity, acceleration and mass included.  No body: steps and reads
+    back nothing (the reference would build a root octant of 0 bodies and dispatch no workgroup)."""
+    nb = gpu
+    s = np.array([[0.1, 0.2, 0.3, 1.0, -2.0, 0.5, 0.25, 0.5, -0.75, 3.0]], np.float32)
+    ref = oracle.tree_step_f32(s, G, E, DT, 0.5)
+    r = run_tree(nb, s, 0.5, 1)
+    assert not r["status"].any()
+    assert np.array_equal(bits(r["dst"]), bits(ref["dst"]))
+    sp = nb.SimParams(particle_num=0)
+    sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), np.zeros((0, 10), np.float32))
+    for _ in range(2):
+        sim.encode()
+        sim.cleanup()
+    sim.wait()
+    assert nb.as_floats(sim.dest_particle_slice()).shape == (0, 10)
+    sim.destroy()
