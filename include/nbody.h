@@ -328,7 +328,7 @@ int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
  * xGMI link), ordered by one HIP event per rank and step -- no host copy, no collective library.
  * Barnes-Hut: replicated tree, partitioned walk -- every device holds the full
  * state and builds the identical octree, walks its range of the sorted bodies, and copies its new
- * position / velocity / acceleration slices into every peer's arrays (peer copies on its stream,
+ * position / velocity / acceleration slices into every peer's arrays (one kernel on its stream, stores through peer access,
  * two events per rank and step); bit for bit the single TreeSim.  (Morton domains + LET exchange,
  * which also shards the build, runs one process per GPU: nb_placement, NB_PHASE_LET_*.)
  * One host thread per rank inside the library; the caller stays single-threaded and every call

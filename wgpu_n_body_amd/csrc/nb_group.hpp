@@ -1,5 +1,5 @@
 // nb_group.hpp -- the one-process multi-GPU runner behind nb_runner_create_multi (all-pairs: peer
-// stores from the finish kernel; Barnes-Hut: replicated tree, partitioned walk, peer copies).
+// stores from the finish kernel; Barnes-Hut: replicated tree, partitioned walk, peer stores).
 #pragma once
 
 #include <memory>
