@@ -330,13 +330,31 @@ int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
  * state and builds the identical octree, walks its range of the sorted bodies, and copies its new
  * position / velocity / acceleration slices into every peer's arrays (one kernel on its stream, stores through peer access,
  * two events per rank and step); bit for bit the single TreeSim.  (Morton domains + LET exchange,
- * which also shards the build, runs one process per GPU: nb_placement, NB_PHASE_LET_*.)
+ * which also shards the build: nb_runner_create_multi_let below, or one process per GPU through
+ * nb_placement and NB_PHASE_LET_*.)
  * One host thread per rank inside the library; the caller stays single-threaded and every call
  * below is synchronous as on one device.  A device id may repeat (ranks sharing a GPU).  n_devices
  * == 1 is nb_runner_create. */
 int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params,
                            const nb_add_params *add_params, nb_init_fn init, void *user,
                            const int *device_ids, int n_devices);
+
+/* Barnes-Hut over several GPUs of this process with the BUILD sharded too: the
+ * bodies are cut into n_devices Morton-range domains at start-up; per step every rank builds the
+ * octree of its own bodies inside the global root cube, exports to every peer the part of that tree
+ * the peer's bodies can need (its locally essential tree, pruned decision-exactly) and walks its own
+ * tree plus the imported ones -- the protocol of NB_PHASE_LET_* below, hosted inside the library: the
+ * bounds, the export counts and the exported records are stored straight into the peers' tables and
+ * import areas through peer access (the counts are consumed on the device), ordered by three events
+ * per rank and step; no host read between migrations.  migrate_every = k > 0: every k-th step the
+ * bodies that left their rank's key range are handed to their new owner (one host read of the
+ * leaver counts on those steps); 0: never.  What a body feels is the sum of per-domain Barnes-Hut
+ * walks, each with the reference's per-body acceptance test (tree.wgsl:57-70): within the walk's
+ * own error of the one-tree result, not bit-equal to it.  nb_runner_read_particles returns the
+ * bodies rank by rank, each rank's in its current tree order.  add_params must be TreeSimParams. */
+int nb_runner_create_multi_let(nb_runner **out, const nb_sim_params *sim_params,
+                               const nb_add_params *add_params, nb_init_fn init, void *user,
+                               const int *device_ids, int n_devices, int migrate_every);
 
 /* `OfflineHeadless::step(&mut self)`, offline_headless.rs:38-44:
  * encode -> submit -> cleanup -> blocking wait. */

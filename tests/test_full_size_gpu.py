@@ -49,6 +49,13 @@ def test_config4_4194304_bodies_let_on_8_domains(gpu, oracle):
     let = nb.as_floats(grp.particles())
     counts = grp.counts
     grp.destroy()
+    # the same step through the C ABI alone (nb_runner_create_multi_let: rank threads inside the library,
+    # records stored into the peers' import areas, counts consumed on the device): the same bits
+    native = nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(theta), lambda _p: p,
+                                device_ids=[0] * world, let_migrate_every=4)
+    native.step()
+    assert np.array_equal(bits(nb.as_floats(native.read_particles())), bits(let))
+    native.destroy()
     assert len(let) == n and np.isfinite(let).all()
     assert np.array_equal(np.sort(let[:, 9]), nb.as_floats(p)[:, 9])        # every body exactly once
     off = ~np.eye(world, dtype=bool)

@@ -500,3 +500,82 @@ def test_energy_and_momentum_after_many_steps_track_all_pairs(gpu, oracle):
         assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 2e-5, name
     single.destroy()
     grp.destroy()
+
+
+# ---- the same protocol hosted inside the library: nb_runner_create_multi_let ---------------------------
+
+@pytest.mark.parametrize("n,world,theta,init,migrate", [(8000, 3, 0.5, "uniform", 0), (20000, 4, 0.5, "uniform", 2),
+                                                         (30000, 8, 0.75, "uniform", 1), (9000, 3, 0.6, "disc", 0),
+                                                         (5000, 2, 0.6, "uniform", 3)])
+def test_native_let_runner_is_the_python_hosted_protocol_bit_for_bit(gpu, n, world, theta, init, migrate):
+    """nb_runner_create_multi_let (C++ rank threads, bounds / counts / records stored into the peers through
+    peer access, counts consumed on the device) against LetGroup above (the protocol driven from
+    Python, exchanges by hipMemcpy, counts read on the host): the same domains, the same kernels,
+    so every rank must hold the same bodies with the same bits in the same order, migration steps
+    included.  The `world` ranks share this box's one GPU (the code path of `world` GPUs)."""
+    nb = gpu
+    sp, p = tagged(nb, n, 31 + world, init)
+    if init == "disc":   # the disc workload of visualize.rs (its velocities are orbits for this g)
+        sp = nb.SimParams(particle_num=n, g=0.00001, dt=0.0016)
+    steps = 7
+    grp = LetGroup(nb, sp, p, world, theta, migrate_every=migrate)
+    native = nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(theta), lambda _p: p,
+                                device_ids=[0] * world, let_migrate_every=migrate)
+    native.step()
+    grp.step()
+    native.step_n(steps - 1)
+    for _ in range(steps - 1):
+        grp.step()
+    assert native.step_num() == steps
+    a, b = nb.as_floats(native.read_particles()), nb.as_floats(grp.particles())
+    native.destroy()
+    moved = grp.migrated
+    grp.destroy()
+    assert np.isfinite(b).all() and len(a) == n
+    assert np.array_equal(bits(a), bits(b))
+    assert len(np.unique(a[:, 9])) == n                     # every body exactly once
+    if migrate == 1:
+        assert moved > 0                                    # the migration path did run
+
+
+def test_native_let_runner_against_the_single_tree(gpu):
+    """... and against ONE TreeSim over all bodies: per-domain walks instead of one walk -- the same
+    physics within the walk's own error (as test_let_gpu's oracle comparisons), bodies matched by tag."""
+    nb = gpu
+    n, world = 40000, 4
+    sp, p = tagged(nb, n, 77)
+    one = nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(0.5), lambda _p: p)
+    let = nb.OfflineHeadless(nb.TreeSim, sp, nb.AddParams.TreeSimParams(0.5), lambda _p: p, device_ids=[0] * world,
+                             let_migrate_every=2)
+    one.step_n(5)
+    let.step_n(5)
+    a, b = by_tag(nb, let.read_particles()), by_tag(nb, one.read_particles())
+    one.destroy()
+    let.destroy()
+    assert np.abs(a[:, 0:3] - b[:, 0:3]).max() < 1e-6
+    err = np.linalg.norm(a[:, 6:9].astype(np.float64) - b[:, 6:9], axis=1) / np.linalg.norm(b[:, 6:9].astype(np.float64), axis=1)
+    assert np.median(err) < 2e-2 and np.percentile(err, 99) < 0.2
+
+
+def test_native_let_runner_reports_a_migration_that_overflows_its_segments(gpu):
+    """A thin disc centred on the root's z = 0 border: a third of a rank's bodies change their top-level
+    octant -- and with it their Morton domain -- within two steps, more than a migration segment
+    (capacity / 8 bodies per destination) holds.  The step must fail with a message, not move a cut-off
+    list (LetTreeSim raises the same way; the remedy is a rebalance)."""
+    nb = gpu
+    sp, p = tagged(nb, 9000, 34, "disc")
+    r = nb.OfflineHeadless(nb.TreeSim, nb.SimParams(particle_num=9000, g=0.00001, dt=0.0016),
+                           nb.AddParams.TreeSimParams(0.6), lambda _p: p, device_ids=[0, 0, 0], let_migrate_every=2)
+    r.step_n(2)
+    with pytest.raises(nb.NBodyError) as ei:
+        r.step()
+    assert "leavers" in str(ei.value)
+    r.destroy()
+
+
+def test_native_let_runner_argument_errors(gpu):
+    nb = gpu
+    sp = nb.SimParams(particle_num=64)
+    with pytest.raises(nb.NBodyError):   # all-pairs has no LET scheme
+        nb.OfflineHeadless(nb.NaiveSim, sp, None, lambda q: nb.inits.uniform_init(q), device_ids=[0, 0],
+                           let_migrate_every=1)

@@ -105,6 +105,20 @@ def main() -> None:
         print(f"{'nb_runner_create_multi tree, n=%d, %d rank(s)' % (n, world):52s} {t / 100 * 1e6:8.1f} us/step", flush=True)
         runner.destroy()
 
+    # ... and with the build sharded too (nb_runner_create_multi_let: Morton domains + LET exchange hosted
+    # in the library; migration every 8th step).  Same caveat: all ranks share this one GPU.
+    for n, world in ((8192, 8), (1 << 20, 2), (1 << 20, 8), (1 << 22, 8)):
+        spn = nb.SimParams(particle_num=n, g=1e-6, e=1e-4, dt=0.016)
+        runner = nb.OfflineHeadless(nb.TreeSim, spn, nb.AddParams.TreeSimParams(0.5),
+                                    lambda p: nb.inits.uniform_init(p, seed=3), device_ids=[0] * world,
+                                    let_migrate_every=8)
+        runner.step_n(24)
+        t0 = time.perf_counter()
+        runner.step_n(64)
+        t = time.perf_counter() - t0
+        print(f"{'nb_runner_create_multi_let, n=%d, %d ranks' % (n, world):52s} {t / 64 * 1e6:8.1f} us/step", flush=True)
+        runner.destroy()
+
 
 if __name__ == "__main__":
     main()

@@ -354,9 +354,12 @@ class OfflineHeadless:
     OfflineHeadless::<NaiveSim>::new(sim_params, add_params, init_fn)."""
 
     def __init__(self, sim_type, sim_params: SimParams, add_params: Optional[AddParams],
-                 init_fn: InitFn, device_id: int = -1, device_ids: Optional[Sequence[int]] = None):
-        """device_ids: several GPUs of this process (nb_runner_create_multi; all-pairs: body ranges + peer stores, TreeSim: replicated tree + partitioned walk): rank r
-        owns a contiguous body range on device_ids[r]; a device id may repeat."""
+                 init_fn: InitFn, device_id: int = -1, device_ids: Optional[Sequence[int]] = None,
+                 let_migrate_every: Optional[int] = None):
+        """device_ids: several GPUs of this process (nb_runner_create_multi; all-pairs: body ranges +
+        peer stores, TreeSim: replicated tree + partitioned walk): rank r owns a contiguous body
+        range on device_ids[r]; a device id may repeat.  let_migrate_every (TreeSim, with device_ids):
+        Morton domains + LET exchange instead (nb_runner_create_multi_let)."""
         L = _lib.lib()
         if add_params is None or add_params.kind != sim_type.KIND:
             add_params = AddParams(sim_type.KIND, 0.0)
@@ -365,8 +368,12 @@ class OfflineHeadless:
         h = C.c_void_p()
         if device_ids is not None:
             ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
-            rc = L.nb_runner_create_multi(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
-                                          ids, len(device_ids))
+            if let_migrate_every is not None:
+                rc = L.nb_runner_create_multi_let(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
+                                                  ids, len(device_ids), int(let_migrate_every))
+            else:
+                rc = L.nb_runner_create_multi(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
+                                              ids, len(device_ids))
         else:
             rc = L.nb_runner_create(C.byref(h), C.byref(sp), C.byref(ap), C.cast(cb, C.c_void_p), None,
                                     int(device_id))
@@ -380,8 +387,9 @@ class OfflineHeadless:
         self.sim = sim_type(sim_h, borrowed=True) if sim_h else None
 
     @classmethod
-    def new(cls, sim_type, sim_params, add_params, init_fn, device_id: int = -1, device_ids=None):
-        return cls(sim_type, sim_params, add_params, init_fn, device_id, device_ids)
+    def new(cls, sim_type, sim_params, add_params, init_fn, device_id: int = -1, device_ids=None,
+            let_migrate_every=None):
+        return cls(sim_type, sim_params, add_params, init_fn, device_id, device_ids, let_migrate_every)
 
     def step_num(self) -> int:
         v = C.c_uint64()

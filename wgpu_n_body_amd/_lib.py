@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "nb_sim_read_tree", "nb_sim_exchange_region", "nb_sim_exchange_count",
     "nb_sim_exchange_region_i", "nb_sim_step_num", "nb_sim_encode_n_timed",
     "nb_sim_set_tuning", "nb_sim_debug_buffer", "nb_naive_variant_count", "nb_naive_variant_name", "nb_sim_destroy",
-    "nb_runner_create", "nb_runner_create_multi", "nb_runner_step_num", "nb_runner_step", "nb_runner_step_n", "nb_runner_read_particles",
+    "nb_runner_create", "nb_runner_create_multi", "nb_runner_create_multi_let", "nb_runner_step_num", "nb_runner_step", "nb_runner_step_n", "nb_runner_read_particles",
     "nb_runner_sim_params", "nb_runner_sim", "nb_runner_destroy",
 ]
 
@@ -119,6 +119,8 @@ def lib() -> C.CDLL:
     L.nb_naive_variant_name.restype = C.c_char_p
     L.nb_runner_create.argtypes = [P(vp), P(nb_sim_params), P(nb_add_params), vp, vp, C.c_int]
     L.nb_runner_create_multi.argtypes = [P(vp), P(nb_sim_params), P(nb_add_params), vp, vp, P(C.c_int), C.c_int]
+    L.nb_runner_create_multi_let.argtypes = [P(vp), P(nb_sim_params), P(nb_add_params), vp, vp, P(C.c_int), C.c_int,
+                                             C.c_int]
     L.nb_runner_step_num.argtypes = [vp, P(u64)]
     L.nb_runner_step.argtypes = [vp]
     L.nb_runner_step_n.argtypes = [vp, C.c_int]

@@ -5,6 +5,7 @@
 //            [--seed K] [--device D | --devices D0,D1,...] [--g G] [--dt DT] [--dump FILE]
 //
 // --devices: the step sharded over several GPUs of this process (nb_runner_create_multi; both simulators);
+// --let K (with --sim tree --devices): Morton domains + LET exchange, migration every K-th step (0: never);
 // a device id may repeat.
 //
 // --dump FILE writes the final state as a snapshot (the layout of
@@ -35,10 +36,10 @@ static bool write_snapshot(const std::string &path, const nbody::SimParams &sp,
 
 template <class Sim>
 static int run(const nbody::SimParams &sp, const nbody::AddParams &ap, const nbody::InitFn &init,
-               int steps, int device, const std::vector<int> &devices, const std::string &dump) {
+               int steps, int device, const std::vector<int> &devices, const std::string &dump, int let) {
     std::puts("Initializing Simulation");
     nbody::OfflineHeadless<Sim> runner = devices.empty() ? nbody::OfflineHeadless<Sim>(sp, ap, init, device)
-                                                         : nbody::OfflineHeadless<Sim>(sp, ap, init, devices);
+                                                         : nbody::OfflineHeadless<Sim>(sp, ap, init, devices, let);
     std::puts("Running Simulation");
     for (int i = 0; i < steps; ++i) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -63,7 +64,7 @@ int main(int argc, char **argv) {
     std::vector<int> devices;
     nbody::SimParams sp{4000000u, 0.000001f, 0.0001f, 0.016f};  // headless.rs:15-20
     float theta = 0.75f;
-    int steps = 10, device = -1;
+    int steps = 10, device = -1, let = -1;
     uint64_t seed = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
@@ -77,6 +78,7 @@ int main(int argc, char **argv) {
         else if (k == "--g") sp.g = (float)std::atof(v.c_str());
         else if (k == "--dt") sp.dt = (float)std::atof(v.c_str());
         else if (k == "--dump") dump = v;
+        else if (k == "--let") let = std::atoi(v.c_str());  // with --devices and --sim tree: LET scheme, migrate every k-th step
         else if (k == "--devices") {
             for (size_t a = 0; a <= v.size();) {
                 const size_t b = std::min(v.find(',', a), v.size());
@@ -91,8 +93,8 @@ int main(int argc, char **argv) {
                                                  : nbody::inits::uniform_init(seed);
     try {
         if (sim == "naive")
-            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device, devices, dump);
-        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device, devices, dump);
+            return run<nbody::NaiveSim>(sp, nbody::AddParams::NaiveSimParams(), fn, steps, device, devices, dump, -1);
+        return run<nbody::TreeSim>(sp, nbody::AddParams::TreeSimParams(theta), fn, steps, device, devices, dump, let);
     } catch (const nbody::Error &e) {
         std::fprintf(stderr, "error %d: %s\n", e.code(), e.what());
         return 1;

@@ -611,15 +611,33 @@ int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
     })
 }
 
+static int runner_create_group(nb_runner **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
+                               nb_init_fn init, void *user, const int *device_ids, int n_devices, int let_migrate_every);
+
 int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
                            nb_init_fn init, void *user, const int *device_ids, int n_devices) {
+    return runner_create_group(out, sim_params, add_params, init, user, device_ids, n_devices, -1);
+}
+
+int nb_runner_create_multi_let(nb_runner **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
+                               nb_init_fn init, void *user, const int *device_ids, int n_devices, int migrate_every) {
+    if (!add_params || add_params->kind != NB_TREE_SIM_PARAMS || migrate_every < 0) {
+        set_error("nb_runner_create_multi_let: TreeSimParams and migrate_every >= 0");
+        return NB_ERR_INVALID;
+    }
+    return runner_create_group(out, sim_params, add_params, init, user, device_ids, n_devices, migrate_every);
+}
+
+static int runner_create_group(nb_runner **out, const nb_sim_params *sim_params, const nb_add_params *add_params,
+                               nb_init_fn init, void *user, const int *device_ids, int n_devices, int let_migrate_every) {
     NB_GUARD({
         if (!out || !sim_params || !init || !device_ids || n_devices < 1) {
             set_error("nb_runner_create_multi: null argument or no device");
             return NB_ERR_INVALID;
         }
         *out = nullptr;
-        if (n_devices == 1) return nb_runner_create(out, sim_params, add_params, init, user, device_ids[0]);
+        if (n_devices == 1 && let_migrate_every < 0)
+            return nb_runner_create(out, sim_params, add_params, init, user, device_ids[0]);
         nb_add_params add;
         add.kind = NB_NAIVE_SIM_PARAMS;
         add.theta = 0.f;
@@ -631,7 +649,8 @@ int nb_runner_create_multi(nb_runner **out, const nb_sim_params *sim_params, con
         std::vector<nb_particle> host(sim_params->particle_num);
         init(sim_params, host.data(), user);  // init_fn(&sim_params) -> Vec<Particle>, once, on the host
         std::unique_ptr<NaiveGroup> g;
-        if (int rc = NaiveGroup::create(g, *sim_params, add, host.data(), device_ids, n_devices)) return rc;
+        if (int rc = NaiveGroup::create(g, *sim_params, add, host.data(), device_ids, n_devices, let_migrate_every))
+            return rc;
         nb_runner *r = new nb_runner();
         r->group = std::move(g);
         *out = r;

@@ -33,7 +33,10 @@
 // single TreeSim.  (The scheme that also shards the build -- Morton domains + LET exchange --
 // runs one process per GPU: wgpu_n_body_amd/sharded.py.)
 #include <atomic>
+#include <algorithm>
+#include <cmath>
 #include <condition_variable>
+#include <numeric>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -74,7 +77,9 @@ struct NaiveGroup::Rank {
     NaiveSim *naive = nullptr;
     int device = 0;
     hipEvent_t done[2] = {nullptr, nullptr};
-    hipEvent_t pushed[2] = {nullptr, nullptr};  // Barnes-Hut: "my slices are in every peer's arrays"
+    hipEvent_t pushed[2] = {nullptr, nullptr};  // Barnes-Hut: "my slices / my LET records are in every peer's arrays"
+    hipEvent_t meta[2] = {nullptr, nullptr};    // LET: "my bounds are in every peer's table"
+    uint32_t active = 0;                        // LET: bodies this rank holds (changes with migration)
     std::thread th;
     int rc = NB_OK;
     std::string err;
@@ -89,6 +94,7 @@ struct NaiveGroup::Shared {
     bool quit = false;
     bool failed = false;   // some rank hit an error: the others stop working but keep meeting
     std::unique_ptr<HostBarrier> bar;
+    std::vector<uint32_t> mig;  // LET migration: world x world leaver counts, row r written by rank r's thread
 };
 
 NaiveGroup::NaiveGroup() : sh_(new Shared()) {}
@@ -108,12 +114,141 @@ NaiveGroup::~NaiveGroup() {
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : r->pushed)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : r->meta)
+            if (e) (void)hipEventDestroy(e);
         r->sim.reset();
     }
 }
 
+// ---- Barnes-Hut with a sharded build: Morton domains + LET exchange --------------
+// The protocol of include/nbody.h (NB_PHASE_LET_*), hosted here instead of in a process per GPU
+// (wgpu_n_body_amd/sharded.py LetTreeSim, whose domain cut and capacities this follows line by line
+// so that both hosts give the same bits).  Per step and rank:
+//   META, my row of bounds stored into every peer's table         -> event "meta"
+//   [all metas in]  BUILD: own octree in the global cube, the part of it every peer needs (LET)
+//   [every peer has finished the previous walk]  my row of export counts + the exported records
+//   stored straight into the peers' tables / import areas (peer access; the counts are read on the
+//   device, the host never sees them)                                                -> event "pushed"
+//   [all records in]  WALK own tree + imported trees, integrate                      -> event "done"
+// No host read between migrations; a migration step (every migrate_every-th) reads the leaver
+// counts on the host, as the Python host does, and pulls the leavers from the peers' send areas.
+namespace {
+uint64_t spread21(uint64_t v) {  // two zero bits after each of the 21 low bits
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+// sharded.py morton_domains(particles, world, slack = 0.02, with_owners = True)
+void morton_domains(const nb_particle *p, size_t n, int world, std::vector<uint32_t> &order, std::vector<size_t> &cuts,
+                    std::vector<unsigned long long> &splits, float &ref_bound) {
+    float amax = 0.f;
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) amax = std::max(amax, std::fabs(p[i].position[c]));
+    const double bound = (double)(float)std::max((double)amax, 1e-30);
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t q[3];
+        for (int c = 0; c < 3; ++c) {
+            double v = ((double)p[i].position[c] + bound) / (2.0 * bound) * 2097152.0;
+            v = std::min(std::max(v, 0.0), 2097151.0);
+            q[c] = (uint64_t)v;
+        }
+        keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    }
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    std::vector<uint64_t> sk(n);
+    for (size_t i = 0; i < n; ++i) sk[i] = keys[order[i]];
+    cuts.assign(1, 0);
+    const long long tol = std::max<long long>(1, (long long)(0.02 * (double)n / (double)std::max(world, 1)));
+    for (int r = 1; r < world; ++r) {
+        const long long c0 = (long long)((n * (size_t)r) / (size_t)world);
+        long long best = c0;
+        const long long lo = std::max(c0 - tol, (long long)cuts.back() + 1), hi = std::min(c0 + tol, (long long)n - 1);
+        if (lo <= hi && n > 1) {
+            for (int level = 1; level < 22; ++level) {  // coarsest first
+                const int shift = 3 * (21 - level);
+                long long found = -1, dist = 0;
+                for (long long j = lo; j <= hi; ++j) {  // a border between bodies j - 1 and j
+                    if ((sk[(size_t)j - 1] >> shift) != (sk[(size_t)j] >> shift)) {
+                        const long long dd = j > c0 ? j - c0 : c0 - j;
+                        if (found < 0 || dd < dist) {  // (numpy argmin: the first of equal distances)
+                            found = j;
+                            dist = dd;
+                        }
+                    }
+                }
+                if (found >= 0) {
+                    best = found;
+                    break;
+                }
+            }
+        }
+        cuts.push_back((size_t)std::max<long long>(best, (long long)cuts.back()));
+    }
+    cuts.push_back(n);
+    splits.clear();
+    for (int r = 1; r < world; ++r) splits.push_back(cuts[(size_t)r] < n ? sk[cuts[(size_t)r]] : (1ull << 63));
+    ref_bound = std::max(amax, 1e-30f);
+}
+}  // namespace
+
+int NaiveGroup::create_let(const nb_sim_params &sp, const nb_add_params &add, const nb_particle *particles,
+                           const int *device_ids, int world) {
+    const size_t n = sp.particle_num;
+    std::vector<uint32_t> order;
+    std::vector<size_t> cuts;
+    std::vector<unsigned long long> splits;
+    float ref_bound = 1.f;
+    morton_domains(particles, n, world, order, cuts, splits, ref_bound);
+    size_t most = 0;
+    for (int r = 0; r < world; ++r) most = std::max(most, cuts[(size_t)r + 1] - cuts[(size_t)r]);
+    const size_t capacity = (size_t)(1.25 * (double)most) + 4096;  // LetTreeSim.HEADROOM
+    if (capacity > 0x7fffffffull) {
+        set_error("LET: too many bodies per rank");
+        return NB_ERR_INVALID;
+    }
+    let_cap_ = (uint32_t)(2 * capacity + 64);   // a peer can need at most this rank's whole octree
+    mig_cap_ = (uint32_t)std::max<size_t>(1024, capacity / 8);  // leavers per destination per migration
+    std::vector<nb_particle> padded(capacity);
+    for (int r = 0; r < world; ++r) {
+        std::unique_ptr<Rank> rk(new Rank());
+        rk->device = device_ids[r];
+        const size_t lo = cuts[(size_t)r], cnt = cuts[(size_t)r + 1] - lo;
+        std::fill(padded.begin(), padded.end(), nb_particle{});
+        for (size_t i = 0; i < cnt; ++i) padded[i] = particles[order[lo + i]];
+        nb_sim_params spl = sp;
+        spl.particle_num = (uint32_t)capacity;
+        nb_placement pl{};
+        pl.device_id = device_ids[r];
+        pl.rank = 0;
+        pl.world = 1;
+        if (int rc = make_sim_impl(rk->sim, &spl, &add, &pl, padded.data(), capacity)) return rc;
+        SimBase &sim = *rk->sim;
+        if (int rc = sim.set_tuning("tree_let_world", world)) return rc;
+        if (int rc = sim.set_tuning("tree_let_rank", r)) return rc;
+        if (int rc = sim.set_tuning("tree_let_active", (int)cnt)) return rc;
+        if (int rc = sim.set_tuning("tree_let_cap", (int)let_cap_)) return rc;
+        if (int rc = sim.let_set_owners(splits.data(), world, ref_bound, mig_cap_)) return rc;
+        rk->active = (uint32_t)cnt;
+        NB_HIP_TRY(hipSetDevice(rk->device));
+        for (hipEvent_t &e : rk->done) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : rk->pushed) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : rk->meta) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ranks_.push_back(std::move(rk));
+    }
+    sh_->mig.assign((size_t)world * (size_t)world, 0u);
+    return NB_OK;
+}
+
 int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
-                       const nb_particle *particles, const int *device_ids, int n_devices) {
+                       const nb_particle *particles, const int *device_ids, int n_devices, int let_migrate_every) {
     if (!device_ids || n_devices < 1 || n_devices > kMaxPeers + 1) {
         set_error("nb_runner_create_multi: between 1 and %d devices", kMaxPeers + 1);
         return NB_ERR_INVALID;
@@ -130,8 +265,19 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
     }
     g->params_ = sp;
     g->tree_ = add.kind == NB_TREE_SIM_PARAMS;
+    g->let_ = g->tree_ && let_migrate_every >= 0;
+    g->migrate_every_ = let_migrate_every > 0 ? let_migrate_every : 0;
     const int world = n_devices;
     for (int r = 0; r < world; ++r) {
+        if (device_ids[r] < 0 || device_ids[r] >= visible) {
+            set_error("device_ids[%d] = %d out of range (%d devices)", r, device_ids[r], visible);
+            return NB_ERR_INVALID;
+        }
+    }
+    if (g->let_) {
+        if (int rc = g->create_let(sp, add, particles, device_ids, world)) return rc;
+    }
+    for (int r = 0; r < world && !g->let_; ++r) {
         if (device_ids[r] < 0 || device_ids[r] >= visible) {
             set_error("device_ids[%d] = %d out of range (%d devices)", r, device_ids[r], visible);
             return NB_ERR_INVALID;
@@ -147,6 +293,7 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
         NB_HIP_TRY(hipSetDevice(rk->device));
         for (hipEvent_t &e : rk->done) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (hipEvent_t &e : rk->pushed) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : rk->meta) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         g->ranks_.push_back(std::move(rk));
     }
     // peer access between every pair of distinct devices, then hand every rank its peers' buffers
@@ -185,6 +332,134 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
     return NB_OK;
 }
 
+// One LET step of rank r (see create_let).  Every rank thread passes the same barriers whatever fails.
+template <typename Fail, typename Failed>
+void NaiveGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
+    Rank &me = *ranks_[r];
+    SimBase &sim = *me.sim;
+    const int world = (int)ranks_.size();
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        set_error("%s failed: %s", what, hipGetErrorString(e));
+        fail(NB_ERR_HIP);
+        return false;
+    };
+    auto region = [&](int q, int k, void **base, size_t *seg) {  // base (and per-rank length) of region k on rank q
+        size_t off = 0, len = 0, total = 0;
+        if (int rc = ranks_[q]->sim->exchange_region(k, base, &off, &len, &total)) {
+            fail(rc);
+            return false;
+        }
+        if (seg) *seg = len;
+        return true;
+    };
+    auto wait_peers = [&](int which, uint64_t idx) {  // 0 meta, 1 pushed, 2 done
+        for (int q = 0; q < world; ++q) {
+            if (q == r) continue;
+            Rank &p = *ranks_[q];
+            hipEvent_t ev = which == 0 ? p.meta[idx & 1] : which == 1 ? p.pushed[idx & 1] : p.done[idx & 1];
+            if (!hip_ok(hipStreamWaitEvent(sim.stream, ev, 0), "hipStreamWaitEvent")) return;
+        }
+    };
+    auto peers_of = [&](int k, void **bases) {  // bases of region k on every peer, in rank order
+        int np = 0;
+        for (int q = 0; q < world; ++q) {
+            if (q == r) continue;
+            if (!region(q, k, &bases[np], nullptr)) return -1;
+            ++np;
+        }
+        return np;
+    };
+
+    const bool migrate = migrate_every_ > 0 && t > 0 && t % (uint64_t)migrate_every_ == 0;
+    if (migrate) {
+        // the bodies that left this rank's key range go to their new owners: leaver counts read on the
+        // host (they size the next launches), leavers pulled from the peers' send areas
+        std::vector<uint32_t> &mig = sh_->mig;
+        if (!failed()) {
+            void *base = nullptr;
+            if (int rc = sim.encode_phase(NB_PHASE_LET_MIGRATE)) fail(rc);
+            else if (hip_ok(hipStreamSynchronize(sim.stream), "hipStreamSynchronize") && region(r, 4, &base, nullptr))
+                (void)hip_ok(hipMemcpy(&mig[(size_t)r * world], static_cast<uint32_t *>(base) + (size_t)r * world,
+                                       sizeof(uint32_t) * (size_t)world, hipMemcpyDeviceToHost), "hipMemcpy");
+        }
+        sh_->bar->wait();  // every row of the table is in
+        if (!failed()) {
+            std::vector<uint32_t> recv((size_t)world, 0u);
+            void *mine = nullptr;
+            bool ok = region(r, 6, &mine, nullptr);
+            size_t at = 0;
+            for (int q = 0; q < world && ok; ++q) {
+                if (q == r) continue;
+                const uint32_t c = mig[(size_t)q * world + r];
+                recv[(size_t)q] = c;
+                if (c > mig_cap_) {
+                    set_error("LET migration: %u leavers from rank %d for rank %d, the segment holds %u", c, q, r, mig_cap_);
+                    fail(NB_ERR_INVALID);
+                    ok = false;
+                    break;
+                }
+                void *theirs = nullptr;
+                size_t seg = 0;
+                if (!region(q, 5, &theirs, &seg)) { ok = false; break; }
+                if (c)
+                    ok = hip_ok(hipMemcpyPeerAsync(static_cast<char *>(mine) + at * 48u, me.device,
+                                                   static_cast<char *>(theirs) + (size_t)r * seg, ranks_[q]->device,
+                                                   (size_t)c * 48u, sim.stream), "hipMemcpyPeerAsync");
+                at += c;
+            }
+            if (ok) {
+                const uint32_t stay = mig[(size_t)r * world + r];
+                if (int rc = sim.let_set_arrivals(stay, recv.data(), world)) fail(rc);
+                else me.active = stay + (uint32_t)at;
+            }
+        }
+    }
+    void *bases[kMaxPeers + 1];
+    if (!failed()) {
+        if (int rc = sim.encode_phase(NB_PHASE_LET_META)) fail(rc);
+        else {
+            const int np = peers_of(0, bases);
+            if (np >= 0) {
+                if (int rc = sim.push_region(0, bases, np)) fail(rc);
+                else (void)hip_ok(hipEventRecord(me.meta[t & 1], sim.stream), "hipEventRecord");
+            }
+        }
+    }
+    sh_->bar->wait();  // every rank has recorded "my bounds are pushed"
+    if (!failed()) {
+        wait_peers(0, t);
+        if (!failed())
+            if (int rc = sim.encode_phase(NB_PHASE_LET_BUILD)) fail(rc);
+        // the peers' tables and import areas are free once they have finished the previous walk
+        if (!failed() && t > 0) wait_peers(2, t - 1);
+        if (!failed()) {
+            const int np = peers_of(1, bases);
+            if (np >= 0)
+                if (int rc = sim.push_region(1, bases, np)) fail(rc);
+        }
+        if (!failed()) {
+            void *imports[kMaxPeers + 1] = {};
+            bool ok = true;
+            for (int q = 0; q < world && ok; ++q)
+                if (q != r) ok = region(q, 3, &imports[q], nullptr);
+            if (ok) {
+                if (int rc = sim.let_push_segments(imports, world, let_cap_)) fail(rc);
+                else (void)hip_ok(hipEventRecord(me.pushed[t & 1], sim.stream), "hipEventRecord");
+            }
+        }
+    }
+    sh_->bar->wait();  // every rank has recorded "my records are pushed"
+    if (!failed()) {
+        wait_peers(1, t);
+        if (!failed()) {
+            if (int rc = sim.let_set_import_stride(let_cap_)) fail(rc);
+            else if (int rc2 = sim.encode_phase(NB_PHASE_LET_WALK)) fail(rc2);
+            else (void)hip_ok(hipEventRecord(me.done[t & 1], sim.stream), "hipEventRecord");
+        }
+    }
+}
+
 // One rank's host thread: waits for a batch of steps, enqueues them, waits for its stream.
 void NaiveGroup::worker(int r) {
     Rank &me = *ranks_[r];
@@ -220,7 +495,8 @@ void NaiveGroup::worker(int r) {
                     e = hipStreamWaitEvent(me.sim->stream, pushed_ev ? ranks_[q]->pushed[idx & 1] : ranks_[q]->done[idx & 1], 0);
             return e;
         };
-        for (int s = 0; s < steps && tree_; ++s) {
+        for (int s = 0; s < steps && let_; ++s) let_step(r, step_ + (uint64_t)s, fail, failed);
+        for (int s = 0; s < steps && tree_ && !let_; ++s) {
             // Barnes-Hut, replicated tree: [peers' slices of step t-1 are in] build + walk my range
             // [every rank has finished step t] copy my slices into every peer's arrays
             const uint64_t t = step_ + (uint64_t)s;
@@ -326,6 +602,21 @@ int NaiveGroup::read_particles(nb_particle *dst, size_t count) {
     if (count > n) {
         set_error("read_particles: asked for %zu of %zu particles", count, n);
         return NB_ERR_INVALID;
+    }
+    if (let_) {  // rank by rank, every rank's bodies in its current tree order (as LetTreeSim.read_particles)
+        size_t at = 0;
+        std::vector<nb_particle> tmp;
+        for (auto &rk : ranks_) {
+            tmp.resize(rk->active);
+            if (rk->active)
+                if (int rc = rk->sim->read_particles(tmp.data(), rk->active)) return rc;
+            for (size_t i = 0; i < rk->active && at < count; ++i) dst[at++] = tmp[i];
+        }
+        if (at < count) {
+            set_error("LET read_particles: the ranks hold %zu bodies, %zu asked for", at, count);
+            return NB_ERR_INVALID;
+        }
+        return NB_OK;
     }
     if (tree_) return ranks_[0]->sim->read_particles(dst, count);  // replicated: every rank holds every body
     std::vector<nb_particle> tmp(n), all(n);

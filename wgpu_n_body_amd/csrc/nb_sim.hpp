@@ -39,6 +39,19 @@ class SimBase {
         set_error("this simulator has no peer push");
         return NB_ERR_UNSUPPORTED;
     }
+    // ... and one small region k (this rank's [off, off + len) of it) into the same place of every peer's
+    // region k (peer_bases[q] = base of region k on peer q): the all-gathers of the LET protocol
+    virtual int push_region(int, void *const *, int) {
+        set_error("this simulator has no peer push");
+        return NB_ERR_UNSUPPORTED;
+    }
+    // LET: the records exported for every peer q (region 2, segment q; as many as the export counted, read
+    // on the device) into peer q's import area (import_bases[q] = base of region 3 on rank q; [me] unused),
+    // at the segment the fixed-stride layout of nb_sim_let_set_import_stride(stride) gives this rank
+    virtual int let_push_segments(void *const *, int, uint32_t) {
+        set_error("let_push_segments: not a TreeSim");
+        return NB_ERR_UNSUPPORTED;
+    }
     virtual int let_set_imports(const uint32_t *, int) {
         set_error("let_set_imports: not a TreeSim");
         return NB_ERR_UNSUPPORTED;

@@ -562,6 +562,18 @@ __global__ __launch_bounds__(256) void push_slices_kernel(const float4 *__restri
     }
 }
 
+// ... a few words (the rank's row of an all-gathered LET table) into every peer's copy of the table
+struct PushWords {
+    uint32_t *p[kMaxPeers];
+    uint32_t n;
+};
+__global__ void push_words_kernel(const uint32_t *__restrict__ src, PushWords dst, uint32_t first, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t v = src[first + i];
+    for (uint32_t q = 0; q < dst.n; ++q) dst.p[q][first + i] = v;
+}
+
 // ---- 5. cells from key prefixes -----------------------------------------------------------------
 // common prefix length in LEVELS of two keys (identical keys are clamped to kLevels-1 so that
 // every cell still has a depth <= kLevels; see the header about colliding keys)
@@ -1882,6 +1894,24 @@ __global__ void let_rebase_fixed_kernel(NodeRec *__restrict__ imp, const uint32_
     imp[i] = rc;
 }
 
+// One-process LET runner (nb_group.cpp): the records exported for peer q go straight into q's import
+// area through peer access -- as many as the export counted (this rank's row of the counts table, read
+// here on the device), to the segment the fixed-stride layout gives this rank on q.  blockIdx.y = q.
+struct LetImportPtrs {
+    NodeRec *p[kLetMaxWorld];
+};
+__global__ __launch_bounds__(256) void let_push_segments_kernel(const NodeRec *__restrict__ send, uint32_t seg_records,
+                                                                const uint32_t *__restrict__ my_counts,
+                                                                LetImportPtrs imports, uint32_t me, uint32_t stride) {
+    const uint32_t q = blockIdx.y;
+    if (q == me) return;
+    const uint32_t count = min(my_counts[q], stride);  // (more than the segment holds: the receiver reports it)
+    const uint32_t j = me < q ? me : me - 1u;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(send + (size_t)q * seg_records);
+    uint4 *d4 = reinterpret_cast<uint4 *>(imports.p[q] + (size_t)j * stride);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count * 2u; i += gridDim.x * blockDim.x) d4[i] = s4[i];
+}
+
 // ---- AoS conversion of the device tree (nb_sim_read_tree) ---------------------------------------
 __global__ void tree_to_aos_kernel(const float4 *__restrict__ cogm, const uint32_t *__restrict__ bodies,
                                    const uint32_t *__restrict__ child, uint32_t n_nodes,
@@ -2721,6 +2751,41 @@ class TreeSim final : public SimBase {
             for (int k = 0; k < 3; ++k) dst.p[k][q] = static_cast<float4 *>(peer_bases[q * 3 + k]);
         hipLaunchKernelGGL(push_slices_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, posm[cur], vel[cur],
                            acc[cur], dst, first, count);
+        NB_HIP_TRY(hipGetLastError());
+        return NB_OK;
+    }
+
+    int push_region(int k, void *const *peer_bases, int npeers) override {
+        void *base = nullptr;
+        size_t off = 0, len = 0, total = 0;
+        if (int rc = exchange_region(k, &base, &off, &len, &total)) return rc;
+        if (npeers < 0 || npeers > kMaxPeers || (off & 3u) || (len & 3u) || len > (1u << 20)) {
+            set_error("push_region: a small table of 4-byte words and at most %d peers", kMaxPeers);
+            return NB_ERR_INVALID;
+        }
+        if (npeers == 0 || len == 0) return NB_OK;
+        if (int rc = bind_device()) return rc;
+        PushWords dst;
+        dst.n = (uint32_t)npeers;
+        for (int q = 0; q < npeers; ++q) dst.p[q] = static_cast<uint32_t *>(peer_bases[q]);
+        const uint32_t count = (uint32_t)(len / 4u);
+        hipLaunchKernelGGL(push_words_kernel, dim3((count + 63u) / 64u), dim3(64), 0, stream,
+                           static_cast<const uint32_t *>(base), dst, (uint32_t)(off / 4u), count);
+        NB_HIP_TRY(hipGetLastError());
+        return NB_OK;
+    }
+
+    int let_push_segments(void *const *import_bases, int world, uint32_t stride) override {
+        if (!let_world || world != let_world || !let_send || stride == 0 || stride > let_cap) {
+            set_error("let_push_segments: needs the LET buffers, tree_let_world ranks and 0 < stride <= tree_let_cap");
+            return NB_ERR_INVALID;
+        }
+        if (world < 2) return NB_OK;
+        if (int rc = bind_device()) return rc;
+        LetImportPtrs imp{};
+        for (int q = 0; q < world; ++q) imp.p[q] = static_cast<NodeRec *>(import_bases[q]);
+        hipLaunchKernelGGL(let_push_segments_kernel, dim3(64, (uint32_t)world), dim3(256), 0, stream, let_send, let_cap,
+                           let_counts + (size_t)let_rank * (size_t)let_world, imp, (uint32_t)let_rank, stride);
         NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }

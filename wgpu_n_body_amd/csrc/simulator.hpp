@@ -197,12 +197,17 @@ class OfflineHeadless {
     }
     // several GPUs of this process (nb_runner_create_multi): rank r owns a contiguous
     // body range on device_ids[r]
-    OfflineHeadless(const SimParams &sp, const AddParams &ap, const InitFn &init, const std::vector<int> &device_ids) {
+    // let_migrate_every >= 0 (TreeSim): Morton domains + LET exchange (nb_runner_create_multi_let)
+    OfflineHeadless(const SimParams &sp, const AddParams &ap, const InitFn &init, const std::vector<int> &device_ids,
+                    int let_migrate_every = -1) {
         detail::InitThunk thunk{&init, {}};
         nb_add_params c = ap.c;
         if (c.kind != T::kKind) c = nb_add_params{T::kKind, 0.f};
-        int rc = nb_runner_create_multi(&r_, &sp, &c, &detail::InitThunk::call, &thunk, device_ids.data(),
-                                        (int)device_ids.size());
+        int rc = let_migrate_every >= 0
+                     ? nb_runner_create_multi_let(&r_, &sp, &c, &detail::InitThunk::call, &thunk, device_ids.data(),
+                                                  (int)device_ids.size(), let_migrate_every)
+                     : nb_runner_create_multi(&r_, &sp, &c, &detail::InitThunk::call, &thunk, device_ids.data(),
+                                              (int)device_ids.size());
         if (!thunk.error.empty()) {
             if (rc == NB_OK) nb_runner_destroy(r_);
             throw Error(NB_ERR_INVALID, thunk.error);
