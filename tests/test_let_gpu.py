@@ -54,7 +54,8 @@ class LetGroup:
     """`world` TreeSims on one GPU running the LET protocol, exchanges by hipMemcpy."""
 
     def __init__(self, nb, sp, particles, world, theta, prune=True, cap=None, migrate_every=0,
-                 own_first=False, fixed_stride=None):
+                 own_first=False, fixed_stride=None, export_mode=None):
+        self.export_mode = export_mode     # tree_let_export_mode: 1 one launch (default), 0 a launch per level
         self.nb, self.world, self.hip = nb, world, _hip()
         self.fixed_stride = fixed_stride   # records per peer moved blindly; counts stay on the device
         self.migrate_every, self.steps_done, self.own_first = migrate_every, 0, own_first
@@ -84,6 +85,8 @@ class LetGroup:
             s.set_tuning("tree_let_rank", r)
             s.set_tuning("tree_let_active", len(mine))
             s.set_tuning("tree_let_prune", 1 if prune else 0)
+            if self.export_mode is not None:
+                s.set_tuning("tree_let_export_mode", self.export_mode)
             s.set_tuning("tree_let_cap", cap or (2 * capacity + 64))
             s.let_set_owners(splits, ref_bound, self.mig_cap)
             self.sims.append(s)
@@ -500,6 +503,29 @@ def test_energy_and_momentum_after_many_steps_track_all_pairs(gpu, oracle):
         assert np.abs(got[:, 0:3] - want[:, 0:3]).max() <= 2e-5, name
     single.destroy()
     grp.destroy()
+
+
+@pytest.mark.parametrize("n,world,theta,init,prune", [(20000, 4, 0.5, "uniform", True), (60000, 8, 0.75, "disc", True),
+                                                       (9000, 3, 0.5, "spherical", False), (700, 5, 0.5, "uniform", True)])
+def test_let_export_in_one_launch_changes_no_bit(gpu, n, world, theta, init, prune):
+    """let_export_kernel (one launch: a workgroup per peer and root child walks its subtree breadth-first)
+    against let_export_level_kernel (a launch per tree level): the segments are laid out differently
+    (the order of the allocations), the records a peer walks are the same -- identical bodies, and
+    identical export counts up to the unused reserved slots of the root's children and grandchildren."""
+    nb = gpu
+    sp, p = tagged(nb, n, 23, init)
+    one = LetGroup(nb, sp, p, world, theta, prune=prune, export_mode=1)
+    per_level = LetGroup(nb, sp, p, world, theta, prune=prune, export_mode=0)
+    for _ in range(3):
+        one.step()
+        per_level.step()
+    a, b = by_tag(nb, one.particles()), by_tag(nb, per_level.particles())
+    ca, cb = one.counts, per_level.counts
+    one.destroy()
+    per_level.destroy()
+    assert np.isfinite(a).all() and np.array_equal(bits(a), bits(b))
+    off = ~np.eye(world, dtype=bool)
+    assert ((ca - cb)[off] >= 0).all() and ((ca - cb)[off] <= 72).all()
 
 
 # ---- the same protocol hosted inside the library: nb_runner_create_multi_let ---------------------------

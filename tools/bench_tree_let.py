@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--init", default="uniform")
     ap.add_argument("--migrate-every", type=int, default=1)
     ap.add_argument("--skip-baselines", action="store_true")
+    ap.add_argument("--export-mode", type=int, default=None, help="tree_let_export_mode: 1 one launch (default), 0 a launch per level")
     ap.add_argument("--count-visits", action="store_true", help="one extra counted step at the end")
     args = ap.parse_args()
     W, n = args.world, args.bodies
@@ -67,6 +68,8 @@ def main() -> None:
         s.set_tuning("tree_let_rank", r)
         s.set_tuning("tree_let_active", len(mine))
         s.set_tuning("tree_let_cap", 2 * capacity + 64)
+        if args.export_mode is not None:
+            s.set_tuning("tree_let_export_mode", args.export_mode)
         s.let_set_owners(splits, ref_bound, mig_cap)
         sims.append(s)
 

@@ -1659,10 +1659,14 @@ __global__ __launch_bounds__(256) void let_meta_kernel(const float4 *__restrict_
 
 // the global root cube: max over ranks of the local bounds (bit patterns of floats >= 1.0)
 __global__ void let_global_bound_kernel(const uint32_t *__restrict__ meta_all, int world,
-                                        uint32_t *__restrict__ bound_bits) {
+                                        uint32_t *__restrict__ bound_bits, uint32_t *__restrict__ my_counts,
+                                        int rank, uint32_t first_free) {
     uint32_t m = __float_as_uint(1.0f);
     for (int r = 0; r < world; ++r) m = max(m, meta_all[r * kLetMetaWords]);
     *bound_bits = m;
+    // every peer's export starts with the root in slot 0 (one-launch export: slots 1..72 reserved too)
+    if (my_counts)
+        for (int r = 0; r < world; ++r) my_counts[r] = r == rank ? 0u : first_free;
 }
 
 // One depth of the export, all peers at once (blockIdx.y = peer).  Node ids are breadth-first
@@ -1742,6 +1746,157 @@ __global__ __launch_bounds__(256) void let_export_level_kernel(
 
 // a peer whose export ran out of room (status[0], an error at the next read-back) still gets a
 // count that fits its segment
+// The whole export in ONE launch (the level-by-level form above is 23 dependent launches whatever the
+// tree's depth: ~115 us of a LET step that takes ~350 at 131,072 bodies per rank).  A workgroup of
+// 1,024 threads exports, for one peer q (blockIdx.y), the subtree under one of the 64 grandchildren
+// (blockIdx.x) of the root, breadth-first: the level's records sit in the peer's segment already (allocated by their
+// parents), each holding -- provisionally, in `first` -- the node it stands for; the workgroup takes
+// them 1,024 at a time, decides terminal / exported with children exactly as above, allocates the
+// children of a chunk with one atomic on the peer's counter and remembers the (base, length) of every
+// allocation in LDS: those ranges are the next level.  Slots 1..72 of a segment are reserved for the
+// root's children and grandchildren (unused ones hold terminals nobody references), which is what
+// lets the 64 subtrees proceed without meeting (with 8 subtrees a workgroup had up to 1/8 of a big
+// export to itself: 400 us instead of 310 for the build + export of 524,288 bodies).  The layout of a segment depends on the order of the atomics; the
+// walk does not (siblings stay consecutive and in octant order, and a lane's partial sums are
+// added across the wave in a fixed order): bit for bit the level-by-level export's result.
+struct LetRange {
+    uint32_t base, len;
+};
+constexpr uint32_t kLetExportThreads = 1024, kLetExportRanges = 3072;  // 2 lists x 24 KiB of LDS
+constexpr uint32_t kLetReserved = 73;  // the root, its 8 children, their 64 children: fixed slots
+
+__device__ __forceinline__ uint32_t let_export_want(const NodeRec &r, const float (&blo)[3], const float (&bhi)[3],
+                                                    float theta2, bool prune, uint32_t n_nodes) {
+    if (r.count == 0u) return 0u;
+    // nearest point of the box to the centre of gravity, per axis, then r^2 in the walk's order
+    const float dx = r.cogm.x - fminf(fmaxf(r.cogm.x, blo[0]), bhi[0]);
+    const float dy = r.cogm.y - fminf(fmaxf(r.cogm.y, blo[1]), bhi[1]);
+    const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
+    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    // some point of the box may open it: export the children too
+    return ((!prune || !(r.ssize2 < theta2 * r2)) && r.first + r.count <= n_nodes) ? r.count : 0u;
+}
+
+__global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
+    const NodeRec *__restrict__ rec, const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
+    const uint32_t *__restrict__ meta_all, int rank, float theta2, bool prune, NodeRec *send,
+    uint32_t *__restrict__ counts, uint32_t cap, uint32_t *__restrict__ status) {
+    const int q = blockIdx.y;
+    const uint32_t sub = blockIdx.x, tid = threadIdx.x;
+    if (q == rank) return;
+    const uint32_t n_nodes = min(*n_nodes_p, n_cap);
+    const uint32_t *mq = meta_all + q * kLetMetaWords;
+    const float blo[3] = {let_ord2f(mq[1]), let_ord2f(mq[2]), let_ord2f(mq[3])};
+    const float bhi[3] = {let_ord2f(mq[4]), let_ord2f(mq[5]), let_ord2f(mq[6])};
+    if (!(blo[0] <= bhi[0]) || n_nodes == 0u) {  // the peer has no bodies / this rank has none: nothing to export
+        if (sub == 0u && tid == 0u) counts[q] = 0u;
+        return;
+    }
+    NodeRec *out = send + (size_t)q * cap;
+    const NodeRec root = rec[0];
+    const uint32_t want0 = cap >= kLetReserved ? let_export_want(root, blo, bhi, theta2, prune, n_nodes) : 0u;
+    const NodeRec dummy{float4{0.f, 0.f, 0.f, 0.f}, 0u, 0u, ~0u, -1.0f};
+    if (sub == 0u && tid < kLetReserved) {
+        // slot 0: the root; 1 + c: child c of the root; 9 + 8 c + j: child j of that child (those that exist
+        // and are exported are written by their own workgroups, the rest hold terminals nobody references)
+        if (tid == 0u) {
+            out[0] = want0 ? NodeRec{root.cogm, 1u, want0, ~0u, root.ssize2} : NodeRec{root.cogm, 0u, 0u, ~0u, -1.0f};
+            if (!want0) counts[q] = 1u;  // (the counter starts at kLetReserved; nobody else touches it then)
+        } else if (want0) {
+            const uint32_t c = tid <= 8u ? tid - 1u : (tid - 9u) >> 3, j = (tid - 9u) & 7u;
+            NodeRec rc = dummy;
+            uint32_t want1 = 0u;
+            if (c < want0) {
+                rc = rec[root.first + c];
+                want1 = let_export_want(rc, blo, bhi, theta2, prune, n_nodes);
+            }
+            if (tid <= 8u) {
+                if (c < want0)
+                    out[tid] = want1 ? NodeRec{rc.cogm, 9u + 8u * c, want1, ~0u, rc.ssize2}
+                                     : NodeRec{rc.cogm, 0u, 0u, ~0u, -1.0f};
+                else
+                    out[tid] = dummy;
+            } else if (j >= want1) {
+                out[tid] = dummy;
+            }
+        }
+    }
+    const uint32_t c = sub >> 3, j = sub & 7u;
+    if (c >= want0) return;
+    const NodeRec rc = rec[root.first + c];
+    if (j >= let_export_want(rc, blo, bhi, theta2, prune, n_nodes)) return;
+    const uint32_t seed_slot = 9u + 8u * c + j, seed_node = rc.first + j;
+
+    __shared__ LetRange s_list[2][kLetExportRanges];
+    __shared__ uint32_t s_n[2], s_wave[kLetExportThreads / 64], s_base;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    if (tid == 0u) {
+        out[seed_slot].first = seed_node;  // provisional: the node this record stands for
+        s_list[0][0] = LetRange{seed_slot, 1u};
+        s_n[0] = 1u;
+        s_n[1] = 0u;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t cur = 0;; cur ^= 1u) {
+        const uint32_t nr = s_n[cur];
+        if (nr == 0u) break;
+        for (uint32_t ri = 0; ri < nr; ++ri) {
+            const LetRange rg = s_list[cur][ri];
+            for (uint32_t off = 0; off < rg.len; off += kLetExportThreads) {
+                const uint32_t i = off + tid, slot = rg.base + i;
+                const bool valid = i < rg.len;
+                NodeRec r{};
+                uint32_t want = 0u;
+                if (valid) {
+                    r = rec[out[slot].first];
+                    want = let_export_want(r, blo, bhi, theta2, prune, n_nodes);
+                }
+                uint32_t incl = want;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t y = __shfl_up(incl, o);
+                    if ((int)lane >= o) incl += y;
+                }
+                if (lane == 63u) s_wave[wave] = incl;
+                __syncthreads();
+                uint32_t before = 0u;
+                for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+                if (tid == 0u) {
+                    uint32_t total = 0u;
+                    for (uint32_t w = 0; w < kLetExportThreads / 64u; ++w) total += s_wave[w];
+                    uint32_t base = 0u;
+                    if (total) {
+                        base = atomicAdd(&counts[q], total);
+                        const uint32_t k = s_n[cur ^ 1u];
+                        if (base + total <= cap && k < kLetExportRanges) {
+                            s_list[cur ^ 1u][k] = LetRange{base, total};
+                            s_n[cur ^ 1u] = k + 1u;
+                        } else {
+                            atomicAdd(&status[0], 1u);  // capacity exceeded: reported by check_status
+                            base = ~0u;                 // (and none of this chunk's cells is exported with children)
+                        }
+                    }
+                    s_base = base;
+                }
+                __syncthreads();
+                if (valid) {
+                    NodeRec o{r.cogm, 0u, 0u, ~0u, -1.0f};  // terminal: a body / pseudo-body for the peer
+                    if (want && s_base != ~0u) {
+                        const uint32_t base = s_base + before + incl - want;
+                        for (uint32_t c = 0; c < want; ++c) out[base + c].first = r.first + c;  // provisional
+                        o = NodeRec{r.cogm, base, want, ~0u, r.ssize2};
+                    }
+                    out[slot] = o;
+                }
+                __threadfence_block();
+                __syncthreads();  // s_wave / s_base are reused; the provisional records are visible
+            }
+        }
+        if (tid == 0u) s_n[cur] = 0u;
+        __syncthreads();
+    }
+}
+
 __global__ void let_clamp_counts_kernel(uint32_t *__restrict__ counts, int world, uint32_t cap) {
     const int q = threadIdx.x;
     if (q < world) counts[q] = min(counts[q], cap);
@@ -2146,20 +2301,23 @@ class TreeSim final : public SimBase {
             NB_HIP_TRY(hipMemsetAsync(my_counts, 0, sizeof(uint32_t) * let_world, stream));
             if (n) {
                 NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 4, stream));
+                // (segments too small for the one-launch export's reserved slots take the level-by-level form)
+                const bool one_launch = let_export_mode == 1u && let_cap >= kLetReserved;
                 hipLaunchKernelGGL(let_global_bound_kernel, dim3(1), dim3(1), 0, stream, let_meta, let_world,
-                                   scalars + 0);
+                                   scalars + 0, my_counts, let_rank, one_launch ? kLetReserved : 1u);
                 if (int rc = enqueue_build(true, true)) return rc;  // (a LET rank's velocities never travel)
-                // every peer's export starts with the root in slot 0
-                std::vector<uint32_t> ones(let_world, 1u);
-                ones[let_rank] = 0u;
-                NB_HIP_TRY(hipMemcpyAsync(my_counts, ones.data(), sizeof(uint32_t) * let_world,
-                                          hipMemcpyHostToDevice, stream));
-                NB_HIP_TRY(hipMemsetAsync(let_out_slot, 0xff, sizeof(uint32_t) * (size_t)let_world * node_cap,
-                                          stream));
-                for (int d = 0; d <= kMaxDepth; ++d)
-                    hipLaunchKernelGGL(let_export_level_kernel, dim3(128, let_world), b256, 0, stream, rec,
-                                       depth_base, d, n_nodes, node_cap, let_meta, let_rank, theta * theta,
-                                       let_prune, let_out_slot, let_send, my_counts, let_cap, status);
+                if (one_launch) {
+                    hipLaunchKernelGGL(let_export_kernel, dim3(64, let_world), dim3(kLetExportThreads), 0, stream, rec,
+                                       n_nodes, node_cap, let_meta, let_rank, theta * theta, let_prune, let_send,
+                                       my_counts, let_cap, status);
+                } else {
+                    NB_HIP_TRY(hipMemsetAsync(let_out_slot, 0xff, sizeof(uint32_t) * (size_t)let_world * node_cap,
+                                              stream));
+                    for (int d = 0; d <= kMaxDepth; ++d)
+                        hipLaunchKernelGGL(let_export_level_kernel, dim3(128, let_world), b256, 0, stream, rec,
+                                           depth_base, d, n_nodes, node_cap, let_meta, let_rank, theta * theta,
+                                           let_prune, let_out_slot, let_send, my_counts, let_cap, status);
+                }
                 hipLaunchKernelGGL(let_clamp_counts_kernel, dim3(1), dim3(64), 0, stream, my_counts, let_world,
                                    let_cap);
                 NB_HIP_TRY(hipGetLastError());
@@ -2851,6 +3009,10 @@ class TreeSim final : public SimBase {
             set_active((uint32_t)value);
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_let_export_mode") == 0) {  // 1: the export in one launch, 0: a launch per tree level
+            let_export_mode = value != 0 ? 1u : 0u;
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_let_prune") == 0) {  // 0: export whole trees (testing: same result)
             let_prune = value != 0;
             return NB_OK;
@@ -2929,6 +3091,7 @@ class TreeSim final : public SimBase {
     int let_world = 0, let_rank = 0, let_next = 0;
     uint32_t let_cap = 0;
     uint32_t *let_meta = nullptr, *let_counts = nullptr, *let_out_slot = nullptr;
+    uint32_t let_export_mode = 1;
     NodeRec *let_send = nullptr;
     LetSegments let_segs{};
     uint32_t let_import_stride = 0;       // != 0: this step's imports are fixed-stride segments
