@@ -2019,8 +2019,11 @@ __global__ void let_rebase_fixed_kernel(NodeRec *__restrict__ imp, const uint32_
                                         uint32_t me, uint32_t world, uint32_t stride, uint32_t import_base,
                                         uint32_t own_root, WalkRoots *__restrict__ roots_dev,
                                         uint32_t *__restrict__ status) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0u) {  // the trees this rank walks: its own (optional), then the non-empty imports in rank order
+    // blockIdx.y = segment (the peers in rank order, this rank left out); the blocks of a segment stride over
+    // its LIVE records only -- the launch does not grow with the stride (the one-process runner's is the
+    // whole tree_let_cap)
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u) {
+        // the trees this rank walks: its own (optional), then the non-empty imports in rank order
         WalkRoots rt{};
         if (own_root) rt.id[rt.count++] = 0u;
         for (uint32_t r = 0; r < world; ++r) {
@@ -2031,22 +2034,24 @@ __global__ void let_rebase_fixed_kernel(NodeRec *__restrict__ imp, const uint32_
         }
         *roots_dev = rt;
     }
-    if (world < 2u || i >= (world - 1u) * stride) return;
-    const uint32_t j = i / stride, local = i - j * stride, r = j < me ? j : j + 1u;
+    if (world < 2u) return;
+    const uint32_t j = blockIdx.y, r = j < me ? j : j + 1u;
     const uint32_t seg_n = min(counts_all[r * world + me], stride);
-    if (local >= seg_n) return;
-    NodeRec rc = imp[i];
-    rc.self_pos = ~0u;
-    if (rc.count != 0u) {
-        if (rc.count <= 8u && rc.first > local && rc.first + rc.count <= seg_n) {
-            rc.first += import_base + j * stride;
-        } else {
-            rc.first = 0u;
-            rc.count = 0u;
-            rc.ssize2 = -1.0f;
+    NodeRec *seg = imp + (size_t)j * stride;
+    for (uint32_t local = blockIdx.x * blockDim.x + threadIdx.x; local < seg_n; local += gridDim.x * blockDim.x) {
+        NodeRec rc = seg[local];
+        rc.self_pos = ~0u;
+        if (rc.count != 0u) {
+            if (rc.count <= 8u && rc.first > local && rc.first + rc.count <= seg_n) {
+                rc.first += import_base + j * stride;
+            } else {
+                rc.first = 0u;
+                rc.count = 0u;
+                rc.ssize2 = -1.0f;
+            }
         }
+        seg[local] = rc;
     }
-    imp[i] = rc;
 }
 
 // One-process LET runner (nb_group.cpp): the records exported for peer q go straight into q's import
@@ -2334,8 +2339,7 @@ class TreeSim final : public SimBase {
         WalkRoots roots{};
         if (let_import_stride) {
             // imports in fixed-stride segments, their counts read on the device (no host round trip)
-            const uint32_t total = (uint32_t)(let_world - 1) * let_import_stride;
-            hipLaunchKernelGGL(let_rebase_fixed_kernel, dim3(std::max(1u, (total + 255u) / 256u)), b256, 0, stream,
+            hipLaunchKernelGGL(let_rebase_fixed_kernel, dim3(64, std::max(1, let_world - 1)), b256, 0, stream,
                                rec + node_cap, let_counts, (uint32_t)let_rank, (uint32_t)let_world,
                                let_import_stride, node_cap, (n && !let_own_walked) ? 1u : 0u, let_roots_dev, status);
             if (n) {
