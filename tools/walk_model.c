@@ -131,6 +131,7 @@ static void walk_group(uint32_t lo, int G, float theta2, Stats *st) {
 // against each of the G bodies, the children of opened cells are pushed (siblings contiguous).
 typedef struct { uint32_t id; uint32_t mask; } CEnt;
 typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any, tpairs, thalves, lo_only, hi_only; } CStats;
+static int g_fifo = 0;  // 1: pop from the OLD end of the list (breadth-first), 0: from the new end (the product)
 static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, CStats *st) {
     static _Thread_local CEnt stack[1 << 16];
     int sp = 0, hw = 0;
@@ -138,7 +139,12 @@ static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, C
     while (sp > 0) {
         const int c = sp < batch ? sp : batch;
         CEnt cur[64];
-        memcpy(cur, stack + sp - c, sizeof(CEnt) * c);
+        if (g_fifo) {
+            memcpy(cur, stack, sizeof(CEnt) * c);
+            memmove(stack, stack + c, sizeof(CEnt) * (sp - c));
+        } else {
+            memcpy(cur, stack + sp - c, sizeof(CEnt) * c);
+        }
         sp -= c;
         st->batches += 1; st->cells += c; st->pairs += (double)batch * G;
         uint32_t any = 0;
@@ -232,7 +238,8 @@ int main(int argc, char **argv) {
         }
     }
 
-    printf("\nscheme C (cells across lanes, G bodies in scalars, LIFO stack, batch 64)\n");
+    for (g_fifo = 0; g_fifo < 2; ++g_fifo) {
+    printf("\nscheme C (cells across lanes, G bodies in scalars, %s, batch 64)\n", g_fifo ? "FIFO queue (breadth-first)" : "LIFO stack");
     const int Gc[4] = {4, 8, 16, 32};
     for (int gi = 0; gi < 4; ++gi) {
         const int G = Gc[gi];
@@ -260,6 +267,8 @@ int main(int argc, char **argv) {
                    tot.visits / tot.cells, tot.tpairs / tot.cells, tot.thalves / tot.cells, 100 * tot.lo_only / tot.cells, 100 * tot.hi_only / tot.cells);
     }
 
+    }
+    g_fifo = 0;
     printf("\nscheme C with cell-aligned groups (a group never straddles a cell of > 8 bodies), G = 8 slots\n");
     {
         // greedy: walk sorted bodies; group = longest run of <= 8 bodies sharing the key prefix of the
