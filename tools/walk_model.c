@@ -130,7 +130,7 @@ static void walk_group(uint32_t lo, int G, float theta2, Stats *st) {
 // LIFO stack of (cell, G-bit visit mask); a batch pops up to 64 cells, every lane tests its cell
 // against each of the G bodies, the children of opened cells are pushed (siblings contiguous).
 typedef struct { uint32_t id; uint32_t mask; } CEnt;
-typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any, tpairs, thalves, lo_only, hi_only; } CStats;
+typedef struct { double batches, cells, pairs, visits, hw, maxhw, pairs_any, tpairs, thalves, lo_only, hi_only, w16, w32; } CStats;
 static int g_fifo = 0;  // 1: pop from the OLD end of the list (breadth-first), 0: from the new end (the product)
 static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, CStats *st) {
     static _Thread_local CEnt stack[1 << 16];
@@ -147,6 +147,7 @@ static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, C
         }
         sp -= c;
         st->batches += 1; st->cells += c; st->pairs += (double)batch * G;
+        if (c <= 16) st->w16 += 1; else if (c <= 32) st->w32 += 1;
         uint32_t any = 0;
         for (int l = 0; l < c; ++l) {
             const Rec *r = &rec[cur[l].id];
@@ -256,6 +257,7 @@ int main(int argc, char **argv) {
                 tot.batches += st.batches; tot.cells += st.cells; tot.pairs += st.pairs; tot.visits += st.visits;
                 tot.hw += st.hw; tot.pairs_any += st.pairs_any; if (st.maxhw > tot.maxhw) tot.maxhw = st.maxhw;
                 tot.tpairs += st.tpairs; tot.thalves += st.thalves; tot.lo_only += st.lo_only; tot.hi_only += st.hi_only;
+                tot.w16 += st.w16; tot.w32 += st.w32;
             }
         }
         const double ngroups = (double)((n64 + stride - 1) / stride) * (64 / G);
@@ -265,6 +267,8 @@ int main(int argc, char **argv) {
         if (G == 8)
             printf("       per popped cell: bodies that visit it %.2f of 8; touched pairs %.2f of 4; touched halves %.2f of 2; lo-half only %.1f %% hi-half only %.1f %%\n",
                    tot.visits / tot.cells, tot.tpairs / tot.cells, tot.thalves / tot.cells, 100 * tot.lo_only / tot.cells, 100 * tot.hi_only / tot.cells);
+        if (G == 8)
+            printf("       batches of <= 16 cells: %.1f %%, of 17..32 cells: %.1f %%\n", 100 * tot.w16 / tot.batches, 100 * tot.w32 / tot.batches);
     }
 
     }
