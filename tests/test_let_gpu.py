@@ -531,7 +531,7 @@ def test_let_export_in_one_launch_changes_no_bit(gpu, n, world, theta, init, pru
 # ---- the same protocol hosted inside the library: nb_runner_create_multi_let ---------------------------
 
 @pytest.mark.parametrize("n,world,theta,init,migrate", [(8000, 3, 0.5, "uniform", 0), (20000, 4, 0.5, "uniform", 2),
-                                                         (30000, 8, 0.75, "uniform", 1), (9000, 3, 0.6, "disc", 0),
+                                                         (30000, 8, 0.75, "uniform", 1), (9000, 3, 0.6, "disc", 0), (3000, 1, 0.5, "uniform", 2),
                                                          (5000, 2, 0.6, "uniform", 3)])
 def test_native_let_runner_is_the_python_hosted_protocol_bit_for_bit(gpu, n, world, theta, init, migrate):
     """nb_runner_create_multi_let (C++ rank threads, bounds / counts / records stored into the peers through

@@ -235,7 +235,8 @@ int NaiveGroup::create_let(const nb_sim_params &sp, const nb_add_params &add, co
         if (int rc = sim.set_tuning("tree_let_rank", r)) return rc;
         if (int rc = sim.set_tuning("tree_let_active", (int)cnt)) return rc;
         if (int rc = sim.set_tuning("tree_let_cap", (int)let_cap_)) return rc;
-        if (int rc = sim.let_set_owners(splits.data(), world, ref_bound, mig_cap_)) return rc;
+        const unsigned long long none = 0;  // (one rank: no border, but not a null pointer)
+        if (int rc = sim.let_set_owners(splits.empty() ? &none : splits.data(), world, ref_bound, mig_cap_)) return rc;
         rk->active = (uint32_t)cnt;
         NB_HIP_TRY(hipSetDevice(rk->device));
         for (hipEvent_t &e : rk->done) NB_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
