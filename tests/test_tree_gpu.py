@@ -122,6 +122,9 @@ def test_tree_and_step_against_oracle(gpu, oracle, kind, n, theta, g, dt):
 # default is 8), and bodies across the lanes with 8 ... 64 bodies per wave (mode 0)
 WALK_SHAPES = [{"tree_walk_mode": 1, "tree_walk_group": 4}, {"tree_walk_mode": 1, "tree_walk_group": 8},
                {"tree_walk_mode": 1, "tree_walk_group": 16},
+               # two-word stack entries (what problems whose cell ids need more than 24 bits take)
+               {"tree_walk_mode": 1, "tree_walk_group": 8, "tree_walk_packed": 0},
+               {"tree_walk_mode": 1, "tree_walk_group": 4, "tree_walk_packed": 0},
                {"tree_walk_mode": 0, "tree_walk_bpw": 8}, {"tree_walk_mode": 0, "tree_walk_bpw": 16},
                {"tree_walk_mode": 0, "tree_walk_bpw": 32}, {"tree_walk_mode": 0, "tree_walk_bpw": 64}]
 
@@ -134,9 +137,10 @@ def test_every_walk_shape_against_oracle(gpu, oracle, kind, n, theta, g, dt):
     and the integer work (tree, order, positions) bit-identical across the shapes."""
     s = make_state(kind, n, 900 + n, g)
     ref = oracle.tree_step_f32(s, g, E, dt, theta, flags=oracle.INTENDED)
-    first = None
+    first, by_shape = None, []
     for shape in WALK_SHAPES:
         r = run_tree(gpu, s, theta, 1, g, E, dt, tuning=shape)
+        by_shape.append(r["dst"])
         assert not r["status"].any(), shape
         check_step(r["dst"], ref["dst"])
         assert abs(int(r["counters"][0]) - ref["stats"]["visits"]) <= max(2, 1e-5 * ref["stats"]["visits"]), shape
@@ -149,6 +153,8 @@ def test_every_walk_shape_against_oracle(gpu, oracle, kind, n, theta, g, dt):
             # the shapes add the same terms in different orders: fp32 rounding apart
             scale = np.abs(first["dst"][:, 6:9]).max()
             assert np.abs(r["dst"][:, 6:9] - first["dst"][:, 6:9]).max() <= 3e-6 * scale, shape
+    # one-word and two-word stack entries are the same traversal: every bit
+    assert np.array_equal(bits(by_shape[1]), bits(by_shape[3])) and np.array_equal(bits(by_shape[0]), bits(by_shape[4]))
 
 
 @pytest.mark.parametrize("core,spread", [(0.5, 2e-3), (0.9, 3e-4)])

@@ -1219,6 +1219,29 @@ __global__ __launch_bounds__(256) void walk_kernel(
 struct CellEnt {
     uint32_t id, mask;  // bit 31 - b of mask: body b of the group has to test the cell
 };
+// PACKED: the two in one word -- the mask uses the top 8 bits (G <= 8), a cell id below 2^24 the rest: half
+// the LDS traffic of the stack (walk -2 % at 2^20 bodies, -3 % at 4 M theta 0.75).  The host picks it
+// when every id the walk can meet (the tree's capacity, the LET import area) is below 2^24.
+constexpr uint32_t kPackedIdBits = 24, kPackedIdMask = (1u << kPackedIdBits) - 1u;
+template <bool PACKED>
+struct CellStack;
+template <>
+struct CellStack<false> {
+    using Ent = CellEnt;
+    static __device__ __forceinline__ Ent make(uint32_t id, uint32_t mask) { return CellEnt{id, mask}; }
+    // the entry of child j of a cell whose first child is `first`
+    static __device__ __forceinline__ Ent child(uint32_t first, uint32_t mask, uint32_t j) { return CellEnt{first + j, mask}; }
+    static __device__ __forceinline__ uint32_t id(const Ent &e) { return e.id; }
+    static __device__ __forceinline__ uint32_t mask(const Ent &e) { return e.mask; }
+};
+template <>
+struct CellStack<true> {
+    using Ent = uint32_t;
+    static __device__ __forceinline__ Ent make(uint32_t id, uint32_t mask) { return id | mask; }
+    static __device__ __forceinline__ Ent child(uint32_t first, uint32_t mask, uint32_t j) { return (first | mask) + j; }
+    static __device__ __forceinline__ uint32_t id(const Ent &e) { return e & kPackedIdMask; }
+    static __device__ __forceinline__ uint32_t mask(const Ent &e) { return e & ~kPackedIdMask; }
+};
 
 // The per-body lane sets come out of the per-lane masks one bit at a time through the carry of an
 // add: v <<= 1, the lanes whose top bit was set are returned as a 64-bit lane mask (one VALU
@@ -1342,7 +1365,7 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
 // roots.id[0 .. split) are walked together and reduced, then roots.id[split .. count): a LET host
 // may walk its own tree (PART 1) while the imports are on the wire and add them later (PART 2),
 // and gets bit for bit what the one-launch step (PART 0) computes.
-template <int G, bool COUNT, int PART>
+template <int G, bool COUNT, int PART, bool PACKED>
 // (G <= 8: at most 96 VGPRs, so that five waves fit a SIMD -- the compiler lands on 90..100 by itself)
 __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAVES : NB_WALK_WAVES)) void walk_cells_kernel(
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
@@ -1358,7 +1381,12 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     // pointer and the whole loop control, which then live in VGPRs under exec masks)
     const uint32_t n_roots =
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->count : roots_arg.count));
-    __shared__ CellEnt s_stack[kCellBlockWaves][kCellStack];
+    using Stack = CellStack<PACKED>;
+    using Ent = typename Stack::Ent;
+    static_assert(!PACKED || G <= 8, "a packed entry has 8 mask bits");
+    // (the stack's LDS also carries the G x 64 floats of the final reduction)
+    constexpr uint32_t kEntries = kCellStack * sizeof(Ent) >= (uint32_t)G * 256u ? kCellStack : (uint32_t)G * 256u / sizeof(Ent);
+    __shared__ Ent s_stack[kCellBlockWaves][kEntries];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t per_xcd = gridDim.x / 8u;  // as walk_kernel: an XCD walks one contiguous eighth
@@ -1405,7 +1433,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     const uint32_t root0 =  // a record every idle lane may read
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->id[0] : roots_arg.id[0]));
     const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
-    CellEnt *stack = s_stack[wave];
+    Ent *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
     if (PART == 2 && owner) {
         const float4 part = acc_dst[ib];
@@ -1424,7 +1452,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
         if (r_lo >= r_hi) continue;
         uint32_t sp = r_hi - r_lo;
         if (lane < sp)
-            stack[lane] = CellEnt{roots_dev ? roots_dev->id[r_lo + lane] : roots_arg.id[r_lo + lane], group_mask};
+            stack[lane] = Stack::make(roots_dev ? roots_dev->id[r_lo + lane] : roots_arg.id[r_lo + lane], group_mask);
         __builtin_amdgcn_wave_barrier();
         v2f ax[G / 2], ay[G / 2], az[G / 2];
 #pragma unroll
@@ -1452,9 +1480,9 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             // idle lanes (a batch of fewer than 64 cells) read a live stack slot and the root's
             // record like everybody else and carry an empty visit mask: no divergent loads
             const bool active = lane < c;
-            const CellEnt top = stack[sp + (active ? lane : 0u)];
-            const uint32_t cell = active ? top.id : root0;
-            const uint32_t vm = active ? top.mask : 0u;  // bodies that test this cell, body b at bit 31 - b
+            const Ent top = stack[sp + (active ? lane : 0u)];
+            const uint32_t cell = active ? Stack::id(top) : root0;
+            const uint32_t vm = active ? Stack::mask(top) : 0u;  // bodies that test this cell, body b at bit 31 - b
 #ifdef NB_DIAG_PHASES
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(cell), "v"(vm));
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -1509,7 +1537,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             const uint32_t cnt = om ? r.count : 0u;
             const uint32_t incl = wave_scan_u32(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            CellEnt *dst = stack + sp + (incl - cnt);
+            Ent *dst = stack + sp + (incl - cnt);
             // Every pushing lane stores all 8 slots, highest first, without looking at its count: a
             // slot past a lane's count lands on a LOWER-numbered slot of a lane above it, which that
             // lane stores later (or beyond the new top, inside the reserve) -- one predicate for
@@ -1517,7 +1545,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             if (cnt != 0u) {
 #pragma unroll
                 for (int j = 7; j >= 0; --j) {
-                    dst[j] = CellEnt{r.first + (uint32_t)j, om};
+                    dst[j] = Stack::child(r.first, om, (uint32_t)j);
                     __builtin_amdgcn_wave_barrier();  // keep the stores in this order
                 }
             }
@@ -2700,19 +2728,24 @@ class TreeSim final : public SimBase {
             const uint32_t gsize = walk_group ? walk_group : 8u;
             const uint32_t per_block = kCellBlockWaves * gsize;
             const dim3 gwalk((hi - lo + per_block - 1) / per_block), bwalk(64 * kCellBlockWaves);
-#define NB_WALK(G, COUNT, PART)                                                                               \
-    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART>), gwalk, bwalk, 0, stream, posm[d], vel[d], acc[d],  \
-                       rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt,     \
+            // one-word stack entries when the group has 8 mask bits and every id is below 2^24
+            const uint64_t id_limit = (uint64_t)node_cap + (let_world ? (uint64_t)let_world * let_cap : 0ull);
+            const bool packed = walk_packed != 0 && gsize <= 8u && id_limit <= (1ull << kPackedIdBits);
+#define NB_WALK(G, COUNT, PART, PACKED)                                                                           \
+    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART, PACKED>), gwalk, bwalk, 0, stream, posm[d], vel[d],      \
+                       acc[d], rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt, \
                        theta, status, counters, bslots, roots_dev)
-#define NB_WALK_P(G, COUNT)                                                                   \
+#define NB_WALK_P(G, COUNT, PACKED)                                                           \
     do {                                                                                      \
-        if (part == 0) NB_WALK(G, COUNT, 0); else if (part == 1) NB_WALK(G, COUNT, 1); else NB_WALK(G, COUNT, 2); \
+        if (part == 0) NB_WALK(G, COUNT, 0, PACKED);                                          \
+        else if (part == 1) NB_WALK(G, COUNT, 1, PACKED);                                     \
+        else NB_WALK(G, COUNT, 2, PACKED);                                                    \
     } while (0)
-#define NB_WALK_G(COUNT)                                          \
-    do {                                                          \
-        if (gsize == 4u) NB_WALK_P(4, COUNT);                     \
-        else if (gsize == 16u) NB_WALK_P(16, COUNT);              \
-        else NB_WALK_P(8, COUNT);                                 \
+#define NB_WALK_G(COUNT)                                                                      \
+    do {                                                                                      \
+        if (gsize == 4u) { if (packed) NB_WALK_P(4, COUNT, true); else NB_WALK_P(4, COUNT, false); }   \
+        else if (gsize == 16u) NB_WALK_P(16, COUNT, false);                                   \
+        else { if (packed) NB_WALK_P(8, COUNT, true); else NB_WALK_P(8, COUNT, false); }      \
     } while (0)
             if (count_visits) NB_WALK_G(true); else NB_WALK_G(false);
 #undef NB_WALK_G
@@ -2968,6 +3001,11 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_walk_packed") == 0) {  // 1: one-word stack entries where the ids allow it (default), 0: never
+            walk_packed = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_walk_group") == 0) {  // bodies per wave of mode 1: 0 = automatic, else 4/8/16
             if (value != 0 && value != 4 && value != 8 && value != 16) {
                 set_error("tree_walk_group must be 0, 4, 8 or 16");
@@ -3084,7 +3122,7 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, sort_items = kSortItems;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
-    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0;
+    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1;
     uint32_t *tile_u32 = nullptr, *run_short = nullptr, *run_long = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
