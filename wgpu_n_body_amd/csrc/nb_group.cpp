@@ -488,8 +488,8 @@ void NaiveGroup::worker(int r) {
             std::lock_guard<std::mutex> lk(sh_->mu);
             return sh_->failed;
         };
-        auto wait_all = [&](hipEvent_t Rank::*arr_unused, bool pushed_ev, uint64_t idx) -> hipError_t {
-            (void)arr_unused;
+        // this rank's stream waits for every peer's event of step idx ("slices pushed" or "step finished")
+        auto wait_all = [&](bool pushed_ev, uint64_t idx) -> hipError_t {
             hipError_t e = hipSuccess;
             for (int q = 0; q < world && e == hipSuccess; ++q)
                 if (q != r)
@@ -503,7 +503,7 @@ void NaiveGroup::worker(int r) {
             const uint64_t t = step_ + (uint64_t)s;
             sh_->bar->wait();  // every rank has recorded its "slices of step t-1 pushed"
             if (!failed()) {
-                hipError_t e = t > 0 ? wait_all(nullptr, true, t - 1) : hipSuccess;
+                hipError_t e = t > 0 ? wait_all(true, t - 1) : hipSuccess;
                 if (e != hipSuccess) {
                     set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
                     fail(NB_ERR_HIP);
@@ -516,7 +516,7 @@ void NaiveGroup::worker(int r) {
             }
             sh_->bar->wait();  // every rank has recorded its "step t finished"
             if (!failed()) {
-                hipError_t e = wait_all(nullptr, false, t);
+                hipError_t e = wait_all(false, t);
                 // positions/masses, velocities, accelerations: one launch stores the slices into every peer
                 void *bases[3 * kMaxPeers];
                 int np = 0;
@@ -543,7 +543,7 @@ void NaiveGroup::worker(int r) {
                 if (int rc = me.sim->encode_phase(0)) fail(rc);  // own j tiles: nothing to wait for
             sh_->bar->wait();  // every rank has recorded its "step t-1 finished"
             if (!failed()) {
-                hipError_t e = t > 0 ? wait_all(nullptr, false, t - 1) : hipSuccess;
+                hipError_t e = t > 0 ? wait_all(false, t - 1) : hipSuccess;
                 if (e != hipSuccess) {
                     set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
                     fail(NB_ERR_HIP);
