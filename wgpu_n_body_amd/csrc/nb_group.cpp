@@ -1,5 +1,5 @@
-// nb_group.cpp -- the all-pairs step on several GPUs of ONE process, behind the C ABI
-// (nb_runner_create_multi): no Python, no torch, no collective library in the step loop.
+// nb_group.cpp -- the step on several GPUs of ONE process, behind the C ABI (nb_runner_create_multi,
+// nb_runner_create_multi_let): no Python, no torch, no collective library in the step loop.
 //
 // There is no reference counterpart: the reference owns one adapter (src/runners/
 // offline_headless.rs:22-31).  What makes the path shard is in the shader itself: naive.wgsl's
@@ -27,11 +27,11 @@
 // Barnes-Hut through the same runner is the replicated-tree scheme of SURVEY 8(e) step 1: every
 // rank holds the full state and builds the identical octree, walks only its range of the sorted
 // bodies, and its new position / velocity / acceleration slices are copied into every peer's
-// arrays (one kernel on the rank's stream, stores through peer access) once EVERY rank has finished the step -- a
-// TreeSim's step reads and writes the same arrays, so the copies must not land while a peer still
+// arrays (one kernel on the rank's stream, stores through peer access) once EVERY rank has
+// finished the step -- a TreeSim's step reads and writes the same arrays, so the copies must not land while a peer still
 // reads them: two events per rank and step ("step finished", "slices pushed").  Bit for bit the
-// single TreeSim.  (The scheme that also shards the build -- Morton domains + LET exchange --
-// runs one process per GPU: wgpu_n_body_amd/sharded.py.)
+// single TreeSim.  The scheme that also shards the build -- Morton domains + LET exchange,
+// nb_runner_create_multi_let -- is hosted here too: see create_let / let_step below.
 #include <atomic>
 #include <algorithm>
 #include <cmath>
