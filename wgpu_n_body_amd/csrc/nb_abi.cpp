@@ -587,7 +587,7 @@ int nb_sim_destroy(nb_sim *sim) {
 // ---- runner: OfflineHeadless<T>, src/runners/offline_headless.rs ---------------------------
 struct nb_runner {
     nb_sim *sim = nullptr;                  // one device
-    std::unique_ptr<NaiveGroup> group;      // several devices of this process (nb_runner_create_multi)
+    std::unique_ptr<DeviceGroup> group;      // several devices of this process (nb_runner_create_multi)
 };
 
 int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
@@ -648,8 +648,8 @@ static int runner_create_group(nb_runner **out, const nb_sim_params *sim_params,
         }
         std::vector<nb_particle> host(sim_params->particle_num);
         init(sim_params, host.data(), user);  // init_fn(&sim_params) -> Vec<Particle>, once, on the host
-        std::unique_ptr<NaiveGroup> g;
-        if (int rc = NaiveGroup::create(g, *sim_params, add, host.data(), device_ids, n_devices, let_migrate_every))
+        std::unique_ptr<DeviceGroup> g;
+        if (int rc = DeviceGroup::create(g, *sim_params, add, host.data(), device_ids, n_devices, let_migrate_every))
             return rc;
         nb_runner *r = new nb_runner();
         r->group = std::move(g);

@@ -72,7 +72,7 @@ class HostBarrier {
 };
 }  // namespace
 
-struct NaiveGroup::Rank {
+struct DeviceGroup::Rank {
     std::unique_ptr<SimBase> sim;
     NaiveSim *naive = nullptr;
     int device = 0;
@@ -85,7 +85,7 @@ struct NaiveGroup::Rank {
     std::string err;
 };
 
-struct NaiveGroup::Shared {
+struct DeviceGroup::Shared {
     std::mutex mu;
     std::condition_variable cv_cmd, cv_done;
     uint64_t cmd_seq = 0;  // bumped by the caller for every batch of steps
@@ -97,9 +97,9 @@ struct NaiveGroup::Shared {
     std::vector<uint32_t> mig;  // LET migration: world x world leaver counts, row r written by rank r's thread
 };
 
-NaiveGroup::NaiveGroup() : sh_(new Shared()) {}
+DeviceGroup::DeviceGroup() : sh_(new Shared()) {}
 
-NaiveGroup::~NaiveGroup() {
+DeviceGroup::~DeviceGroup() {
     {
         std::lock_guard<std::mutex> lk(sh_->mu);
         sh_->quit = true;
@@ -199,7 +199,7 @@ void morton_domains(const nb_particle *p, size_t n, int world, std::vector<uint3
 }
 }  // namespace
 
-int NaiveGroup::create_let(const nb_sim_params &sp, const nb_add_params &add, const nb_particle *particles,
+int DeviceGroup::create_let(const nb_sim_params &sp, const nb_add_params &add, const nb_particle *particles,
                            const int *device_ids, int world) {
     const size_t n = sp.particle_num;
     std::vector<uint32_t> order;
@@ -248,7 +248,7 @@ int NaiveGroup::create_let(const nb_sim_params &sp, const nb_add_params &add, co
     return NB_OK;
 }
 
-int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
+int DeviceGroup::create(std::unique_ptr<DeviceGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
                        const nb_particle *particles, const int *device_ids, int n_devices, int let_migrate_every) {
     if (!device_ids || n_devices < 1 || n_devices > kMaxPeers + 1) {
         set_error("nb_runner_create_multi: between 1 and %d devices", kMaxPeers + 1);
@@ -259,7 +259,7 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
         set_error("no HIP device is visible (hipGetDeviceCount); there is no CPU fallback");
         return NB_ERR_NO_DEVICE;
     }
-    std::unique_ptr<NaiveGroup> g(new (std::nothrow) NaiveGroup());
+    std::unique_ptr<DeviceGroup> g(new (std::nothrow) DeviceGroup());
     if (!g) {
         set_error("out of host memory");
         return NB_ERR_ALLOC;
@@ -328,14 +328,14 @@ int NaiveGroup::create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp
         if (int rc = g->ranks_[r]->naive->set_peers(b0, b1, k)) return rc;
     }
     g->sh_->bar.reset(new HostBarrier(world));
-    for (int r = 0; r < world; ++r) g->ranks_[r]->th = std::thread(&NaiveGroup::worker, g.get(), r);
+    for (int r = 0; r < world; ++r) g->ranks_[r]->th = std::thread(&DeviceGroup::worker, g.get(), r);
     out = std::move(g);
     return NB_OK;
 }
 
 // One LET step of rank r (see create_let).  Every rank thread passes the same barriers whatever fails.
 template <typename Fail, typename Failed>
-void NaiveGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
+void DeviceGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
     Rank &me = *ranks_[r];
     SimBase &sim = *me.sim;
     const int world = (int)ranks_.size();
@@ -462,7 +462,7 @@ void NaiveGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
 }
 
 // One rank's host thread: waits for a batch of steps, enqueues them, waits for its stream.
-void NaiveGroup::worker(int r) {
+void DeviceGroup::worker(int r) {
     Rank &me = *ranks_[r];
     const int world = (int)ranks_.size();
     (void)hipSetDevice(me.device);
@@ -565,7 +565,7 @@ void NaiveGroup::worker(int r) {
     }
 }
 
-int NaiveGroup::step_n(int steps) {
+int DeviceGroup::step_n(int steps) {
     if (steps <= 0) return NB_OK;
     {
         std::lock_guard<std::mutex> lk(sh_->mu);
@@ -591,14 +591,14 @@ int NaiveGroup::step_n(int steps) {
     return NB_OK;
 }
 
-std::string NaiveGroup::first_error() const {
+std::string DeviceGroup::first_error() const {
     for (auto &r : ranks_)
         if (r->rc != NB_OK) return r->err;
     return "";
 }
 
 // All positions/masses are everywhere; velocities and accelerations live with their owner.
-int NaiveGroup::read_particles(nb_particle *dst, size_t count) {
+int DeviceGroup::read_particles(nb_particle *dst, size_t count) {
     const size_t n = params_.particle_num;
     if (count > n) {
         set_error("read_particles: asked for %zu of %zu particles", count, n);

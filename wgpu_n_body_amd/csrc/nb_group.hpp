@@ -11,13 +11,13 @@
 
 namespace nb {
 
-class NaiveGroup {
+class DeviceGroup {
    public:
-    ~NaiveGroup();
+    ~DeviceGroup();
     // bodies [r per, (r+1) per) on device_ids[r]; a device id may repeat (ranks sharing a GPU)
     // let_migrate_every < 0: Barnes-Hut as replicated tree; >= 0: Morton domains + LET exchange (0: bodies never
     // change their rank, k: the bodies that left their rank's key range are handed over every k-th step)
-    static int create(std::unique_ptr<NaiveGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
+    static int create(std::unique_ptr<DeviceGroup> &out, const nb_sim_params &sp, const nb_add_params &add,
                       const nb_particle *particles, const int *device_ids, int n_devices, int let_migrate_every = -1);
     int step_n(int steps);  // enqueue on every rank, return when every rank has finished
     int read_particles(nb_particle *dst, size_t count);
@@ -26,7 +26,7 @@ class NaiveGroup {
     uint64_t step_num() const { return step_; }
 
    private:
-    NaiveGroup();
+    DeviceGroup();
     struct Rank;
     struct Shared;
     void worker(int r);
