@@ -703,26 +703,25 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
     if (threadIdx.x == 0) tile_mom[blockIdx.x] = msum;
 }
 
-// B: exclusive scan over the tiles of every row (one wave per row, lanes take contiguous segments)
+// B: exclusive scan over the tiles of every row.  A workgroup per row (blockIdx.x < kCellRows: the row's
+// total goes to row_total[row]; the depth bases that follow from the totals are derived by C itself) and
+// four more for the four moment sums -- round 2's first form did all rows in ONE workgroup, 10 us at 2^20 bodies, 31 at
+// 4 M, 124 at 16 M; the rows do not depend on each other.
 __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__ tile_u32,
-                                                          Moments *__restrict__ tile_mom, uint32_t ntiles,
-                                                          uint32_t stride,
-                                                          uint32_t *__restrict__ depth_base,
-                                                          uint32_t *__restrict__ n_nodes, uint32_t cap,
-                                                          uint32_t *__restrict__ status,
-                                                          uint32_t *__restrict__ bound_slots,
-                                                          uint32_t *__restrict__ run_counts) {
-    __shared__ uint32_t s_total[kCellRows];
-    if (threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
-    if (threadIdx.x < 2u) run_counts[threadIdx.x] = 0u;           // the next step's sort fix-up lists
+                                                         Moments *__restrict__ tile_mom, uint32_t ntiles,
+                                                         uint32_t stride, uint32_t *__restrict__ row_total,
+                                                         uint32_t *__restrict__ bound_slots,
+                                                         uint32_t *__restrict__ run_counts) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // a wave takes a row in chunks of 256 tiles: every lane 4 consecutive tiles (one 16-byte
-    // access; rows are padded to a multiple of 4 words), a wave scan of the lane sums, a carry
-    for (uint32_t r = wave; r < kCellRows; r += 16u) {
-        uint4 *row = reinterpret_cast<uint4 *>(tile_u32 + (size_t)r * stride);
+    if (blockIdx.x < kCellRows) {
+        // the row in chunks of 4,096 tiles: a wave 256 of them, every lane 4 consecutive tiles (one 16-byte
+        // access; rows are padded to a multiple of 4 words), a wave scan of the lane sums, the waves'
+        // totals through LDS, a carry
+        __shared__ uint32_t s_w[16];
+        uint4 *row = reinterpret_cast<uint4 *>(tile_u32 + (size_t)blockIdx.x * stride);
         uint32_t carry = 0;
-        for (uint32_t base = 0; base < stride; base += 256u) {
-            const uint32_t i4 = base / 4u + lane;
+        for (uint32_t base = 0; base < stride; base += 4096u) {
+            const uint32_t i4 = base / 4u + threadIdx.x;
             uint4 v{0u, 0u, 0u, 0u};
             if (i4 * 4u < stride) v = row[i4];
             if (i4 * 4u + 0u >= ntiles) v.x = 0u;  // (the padding of the row was never written)
@@ -735,46 +734,50 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
                 const uint32_t y = __shfl_up(x, o);
                 if ((int)lane >= o) x += y;
             }
-            const uint32_t run = carry + x - sum;
+            if (lane == 63u) s_w[wave] = x;
+            __syncthreads();
+            uint32_t before = 0u, chunk_total = 0u;
+            for (uint32_t w = 0; w < 16u; ++w) {
+                before += w < wave ? s_w[w] : 0u;
+                chunk_total += s_w[w];
+            }
+            const uint32_t run = carry + before + x - sum;
             if (i4 * 4u < stride) row[i4] = uint4{run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z};
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+            carry += chunk_total;
+            __syncthreads();  // s_w is reused
         }
-        if (lane == 0u) s_total[r] = carry;
+        if (threadIdx.x == 0u) row_total[blockIdx.x] = carry;
+        return;
     }
-    {   // the moments, by all 1,024 threads in a fixed order: thread t sums the tiles [t S, (t+1) S) in
+    const uint32_t comp = blockIdx.x - kCellRows;  // 0..3: m x, m y, m z, m -- a workgroup per component
+    if (comp == 0u) {
+        if (threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
+        if (threadIdx.x < 2u) run_counts[threadIdx.x] = 0u;           // the next step's sort fix-up lists
+    }
+    {   // the moments, by the 1,024 threads in a fixed order: thread t sums the tiles [t S, (t+1) S) in
         // order, the threads' sums are scanned by wave (fixed shuffle tree) and the waves' totals
         // added in wave order -- deterministic whatever the launch timing
-        __shared__ Moments s_wtot[16];
+        __shared__ double s_wtot[16];
+        double *vals = reinterpret_cast<double *>(tile_mom) + comp;  // stride 4 doubles
         const uint32_t per = (ntiles + 1023u) / 1024u;
         const uint32_t t_lo = min(threadIdx.x * per, ntiles), t_hi = min(t_lo + per, ntiles);
-        Moments sum{0, 0, 0, 0};
-        for (uint32_t i = t_lo; i < t_hi; ++i) sum = sum + tile_mom[i];
-        Moments x = sum;
+        double sum = 0.0;
+        for (uint32_t i = t_lo; i < t_hi; ++i) sum += vals[4u * (size_t)i];
+        double x = sum;
         for (int o = 1; o < 64; o <<= 1) {
-            Moments y{__shfl_up(x.x, o), __shfl_up(x.y, o), __shfl_up(x.z, o), __shfl_up(x.m, o)};
-            if ((int)lane >= o) x = x + y;
+            const double y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
         }
         if (lane == 63u) s_wtot[wave] = x;
         __syncthreads();
-        Moments run{0, 0, 0, 0};
-        for (uint32_t w = 0; w < wave; ++w) run = run + s_wtot[w];
-        run = run + Moments{x.x - sum.x, x.y - sum.y, x.z - sum.z, x.m - sum.m};
+        double run = 0.0;
+        for (uint32_t w = 0; w < wave; ++w) run += s_wtot[w];
+        run += x - sum;
         for (uint32_t i = t_lo; i < t_hi; ++i) {
-            const Moments v = tile_mom[i];
-            tile_mom[i] = run;
-            run = run + v;
+            const double v = vals[4u * (size_t)i];
+            vals[4u * (size_t)i] = run;
+            run += v;
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // depth_base[d] = nodes of depth < d; [kMaxDepth + 1] = node count
-        uint32_t run = 0;
-        for (int d = 0; d <= kMaxDepth; ++d) {
-            depth_base[d] = run;
-            run += s_total[1 + d];
-        }
-        depth_base[kMaxDepth + 1] = run;
-        *n_nodes = run;
-        if (run > cap) atomicAdd(&status[1], 1u);
     }
 }
 
@@ -782,7 +785,8 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
 // BFS allocation order), slots of the opened cells, moment prefixes
 __global__ __launch_bounds__(256) void cells_c_kernel(
     const int8_t *__restrict__ cpl, uint32_t n, const uint32_t *__restrict__ tile_u32,
-    const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ depth_base,
+    const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ row_total,
+    uint32_t *__restrict__ depth_base, uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ status,
     const float4 *__restrict__ posm, uint32_t *__restrict__ int_slot, uint32_t *__restrict__ leaf_id,
     uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
     Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds, const uint32_t *__restrict__ order,
@@ -792,8 +796,28 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
     __shared__ Moments s_wave[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    if (threadIdx.x <= kMaxDepth)  // where this tile's nodes of depth d start
-        s_run[threadIdx.x] = depth_base[threadIdx.x] + tile_u32[(size_t)(1 + threadIdx.x) * stride + blockIdx.x];
+    if (wave == 0u) {
+        // depth_base[d] = nodes of depth < d, from the rows' totals (row 1 + d = depth d); [kMaxDepth + 1] = the
+        // node count.  Every workgroup derives them for itself; the first one publishes them for the kernels
+        // that follow (fill, LET export, read-out) and checks the 4N capacity.
+        const uint32_t mine = lane <= (uint32_t)kMaxDepth ? row_total[1u + lane] : 0u;
+        uint32_t x = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        const uint32_t base_d = x - mine;  // exclusive
+        if (lane <= (uint32_t)kMaxDepth)  // where this tile's nodes of depth d start
+            s_run[lane] = base_d + tile_u32[(size_t)(1u + lane) * stride + blockIdx.x];
+        if (blockIdx.x == 0u) {
+            if (lane <= (uint32_t)kMaxDepth) depth_base[lane] = base_d;
+            if (lane == (uint32_t)kMaxDepth) {
+                depth_base[kMaxDepth + 1] = x;
+                *n_nodes = x;
+                if (x > cap) atomicAdd(&status[1], 1u);
+            }
+        }
+    }
     uint32_t slot_run = tile_u32[blockIdx.x];  // row 0: opened cells before this tile
     Moments mom_run = tile_mom[blockIdx.x];
     __syncthreads();
@@ -2668,10 +2692,11 @@ class TreeSim final : public SimBase {
         const uint32_t cstride = (ct + 3u) & ~3u;  // rows of the tile table, padded to 16 bytes
         hipLaunchKernelGGL(cells_a_kernel, dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys, cpl,
                            tile_u32, tile_mom, cstride, rounds, status);
-        hipLaunchKernelGGL(cells_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
-                           depth_base, n_nodes, node_cap, status, bound_slots, scalars + 12);
-        hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, depth_base,
-                           posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
+        uint32_t *row_total = scalars + 40;  // kCellRows words
+        hipLaunchKernelGGL(cells_scan_kernel, dim3(kCellRows + 4), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
+                           row_total, bound_slots, scalars + 12);
+        hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
+                           depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
                            rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
         va_gathered = with_va;
         // 6: node contents
