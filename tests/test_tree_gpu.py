@@ -440,8 +440,8 @@ def test_tree_step_in_two_phases(gpu):
                                     (600000, "uniform"), (600000, "disc")])
 def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
     """Above 16,384 bodies the radix sort covers only the high key bits (3 passes of 8 bits at 20,000
-    and 100,000 bodies, 4 at 600,000) and fixes the runs that tie there up afterwards;
-    `tree_sort_mode` 0 runs eight passes over the whole key instead.  Both must give the same stable
+    and 100,000 bodies, 4 at 600,000 -- 3 of 9 bits with `tree_sort_wide` 1) and fixes the runs
+    that tie there up afterwards; `tree_sort_mode` 0 runs seven 9-bit passes over the whole key instead.  Both must give the same stable
     order by key (which the oracle pins at <= 20,000 bodies above and at 2^20 / 4 M / 8 M bodies in
     test_full_size_gpu.py): body order, tree and new state bit for bit the same, after 2 steps (the
     second sorts a state that is already in sorted order; the disc has thousands of runs)."""
@@ -450,7 +450,9 @@ def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
     state = nb.as_floats(getattr(nb.inits, init + "_init")(sp, seed=n % 97))
     a = run_tree(nb, state, 0.75, steps=2, count=False)
     b = run_tree(nb, state, 0.75, steps=2, count=False, tuning={"tree_sort_mode": 0})
-    assert not a["status"].any() and not b["status"].any()
+    c = run_tree(nb, state, 0.75, steps=2, count=False, tuning={"tree_sort_wide": 1})   # 9-bit digits where they save a pass
+    assert not a["status"].any() and not b["status"].any() and not c["status"].any()
+    assert np.array_equal(a["order"], c["order"]) and np.array_equal(bits(a["dst"]), bits(c["dst"]))
     assert np.array_equal(a["order"], b["order"])
     assert np.array_equal(np.sort(a["order"]), np.arange(n, dtype=np.uint32))
     assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]

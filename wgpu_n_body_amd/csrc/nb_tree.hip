@@ -53,7 +53,7 @@ constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 gua
 // bodies per thread of a sort tile: 4 up to kSortSmallMax bodies (more, smaller workgroups: build
 // -13 us at 131,072 bodies, -5 at 524,288), 8 beyond (half the histogram rows: -14 us at 2^20, -40 at 2^21)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortItemsSmall = 4, kSortSmallMax = 786432;
-constexpr uint32_t kSortBits = 8, kSortMaxBins = 1u << kSortBits;  // digit width (the kernels take 7..9)
+constexpr uint32_t kSortBits = 8, kSortWideBits = 9, kSortMaxBins = 1u << kSortWideBits;  // digit widths (the kernels take 7..9)
 constexpr uint32_t kSortInlineScanBlocks = 32;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
 // wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
 // most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
@@ -103,7 +103,7 @@ __device__ __forceinline__ void publish_bound(uint32_t *__restrict__ slots, uint
 // bound_src: where the root cube's half width comes from -- scalars[0] (bound_kernel / the LET
 // maximum; n_src = 1) or the kBoundSlots words accumulated by the previous step's walk (n_src =
 // kBoundSlots); it is republished in scalars[0].
-__global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__restrict__ posm, uint32_t n,
+__global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *__restrict__ posm, uint32_t n,
                                                               const uint32_t *__restrict__ bound_src,
                                                               uint32_t n_src, uint32_t *__restrict__ bound_bits,
                                                               uint64_t *__restrict__ keys,
@@ -111,11 +111,11 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
                                                               uint32_t *__restrict__ hist, uint32_t nblocks,
                                                               uint32_t items, uint32_t hist_shift,
                                                               uint32_t hist_bins) {
-    // (items = kSortItems: a workgroup is a sort tile and leaves the tile's histogram of the digit the
+    // (blockDim.x * items bodies = a sort tile: a workgroup leaves the tile's histogram of the digit the
     // FIRST radix pass sorts by -- hist_bins values at bit hist_shift; the counting sort of small
     // problems needs no histogram and takes items = 1: more, shorter workgroups)
     __shared__ uint32_t s_hist[kSortMaxBins];
-    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += kSortThreads) s_hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
     uint32_t bmax = 0;
     for (uint32_t k = 0; k < n_src; ++k) bmax = max(bmax, bound_src[k]);
@@ -127,12 +127,12 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
     float4 pv[kSortItems];
 #pragma unroll
     for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = (blockIdx.x * items + c) * kSortThreads + threadIdx.x;
+        const uint32_t i = (blockIdx.x * items + c) * blockDim.x + threadIdx.x;
         if (c < items && i < n) pv[c] = posm[i];
     }
 #pragma unroll
     for (uint32_t c = 0; c < kSortItems; ++c) {
-        const uint32_t i = (blockIdx.x * items + c) * kSortThreads + threadIdx.x;
+        const uint32_t i = (blockIdx.x * items + c) * blockDim.x + threadIdx.x;
         if (c >= items || i >= n) break;
         const float4 p = pv[c];
         float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kSortThreads) void morton_kernel(const float4 *__re
     }
     __syncthreads();
     if (hist)
-        for (uint32_t b = threadIdx.x; b < hist_bins; b += kSortThreads) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
+        for (uint32_t b = threadIdx.x; b < hist_bins; b += blockDim.x) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
 }
 
 // ---- 3. radix sort (LSD, digits of W bits, pairs) ------------------------------------------------
@@ -2621,8 +2621,9 @@ class TreeSim final : public SimBase {
         // 3 / 3d: stable radix passes of kSortBits bits -- over all 63 key bits, or (sort_mode 1) only
         // over the top `bits` bits, such that a cell of that level holds 1/64 body on average
         // (2^bits >= 64 N), followed by the fix-up of the runs that tie there.
-        // (Digits of 9 bits -- 3 passes instead of 4 at 2^20 bodies -- were measured and dropped: the
-        // scatter of a pass costs 17 instead of 12 us and the fix-up sees 30x the runs,
+        // Digits of 8 bits.  (9 where that saves a pass -- 25..27 bits: 262,145 .. 2,097,152 bodies -- is tuning
+        // key "tree_sort_wide": measured twice and not faster, a 9-bit scatter costs 17 instead of 13 us at
+        // 2^20 bodies and the fix-up sees 30x the runs, which eats the pass saved:
         // profiles/r02_sort_experiments.txt.)
         uint32_t bits = 63;
         if (sort_mode == 1) {
@@ -2630,7 +2631,9 @@ class TreeSim final : public SimBase {
             while ((1ull << bits) < 64ull * n) ++bits;
             bits = std::min(63u, std::max(21u, bits));
         }
-        constexpr uint32_t W = kSortBits, bins = 1u << W;
+        const uint32_t W = (bits + kSortWideBits - 1u) / kSortWideBits < (bits + kSortBits - 1u) / kSortBits && sort_wide
+                               ? kSortWideBits : kSortBits;
+        const uint32_t bins = 1u << W;
         const uint32_t passes = (bits + W - 1u) / W;
         const uint32_t shift0 = 63u > passes * W ? 63u - passes * W : 0u;  // the passes cover bits shift0 .. 62
         if (rank_sort)
@@ -2638,8 +2641,10 @@ class TreeSim final : public SimBase {
                                posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u,
                                0u, 1u);
         else  // (with the tile histograms of the first pass's digit)
-            hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(kSortThreads), 0, stream, posm[s], n, bound_src,
-                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items, shift0, bins);
+            // (512 threads x half the sort's items per thread: the same tile, twice the waves per SIMD for the
+            // 21 dependent levels of the key descent)
+            hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(2 * kSortThreads), 0, stream, posm[s], n, bound_src,
+                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items / 2u, shift0, bins);
         int kb = 0;
         if (rank_sort) {
             // 3c: the sorted position of every body counted in one launch
@@ -2650,23 +2655,29 @@ class TreeSim final : public SimBase {
             for (uint32_t ps = 0; ps < passes; ++ps) {
                 const uint32_t shift = shift0 + ps * W;
                 const bool inl = sort_blocks <= kSortInlineScanBlocks;
-#define NB_PASS(ITEMS)                                                                                              \
+#define NB_PASS(WW, ITEMS)                                                                                          \
     do {                                                                                                            \
         if (ps != 0u)                                                                                               \
             hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(sort_blocks), dim3(kSortThreads), 0, stream,        \
                                keys[kb], n, shift, bins, hist, sort_blocks);                                        \
         if (inl) {                                                                                                  \
-            hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, ITEMS, true>), dim3(sort_blocks),                   \
+            hipLaunchKernelGGL((radix_scatter_kernel<WW, ITEMS, true>), dim3(sort_blocks),                          \
                                dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
                                shift, hist, totals, sort_blocks);                                                   \
         } else {                                                                                                    \
             hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);            \
-            hipLaunchKernelGGL((radix_scatter_kernel<kSortBits, ITEMS, false>), dim3(sort_blocks),                  \
+            hipLaunchKernelGGL((radix_scatter_kernel<WW, ITEMS, false>), dim3(sort_blocks),                         \
                                dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
                                shift, hist, totals, sort_blocks);                                                   \
         }                                                                                                           \
     } while (0)
-                if (sort_items == kSortItemsSmall) NB_PASS(kSortItemsSmall); else NB_PASS(kSortItems);
+                if (W == kSortWideBits) {
+                    if (sort_items == kSortItemsSmall) NB_PASS(kSortWideBits, kSortItemsSmall);
+                    else NB_PASS(kSortWideBits, kSortItems);
+                } else {
+                    if (sort_items == kSortItemsSmall) NB_PASS(kSortBits, kSortItemsSmall);
+                    else NB_PASS(kSortBits, kSortItems);
+                }
 #undef NB_PASS
                 kb ^= 1;
             }
@@ -3049,6 +3060,11 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_sort_wide") == 0) {  // 1: 9-bit digits where they save a pass, 0: always 8 (default)
+            sort_wide = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: counting sort (<= 16,384 bodies) / high digits + fix-up;
                                                         // 0: always the full 8-pass radix sort
             sort_mode = value != 0 ? 1u : 0u;
@@ -3147,7 +3163,7 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, sort_items = kSortItems;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
-    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1;
+    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1, sort_wide = 0;
     uint32_t *tile_u32 = nullptr, *run_short = nullptr, *run_long = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
