@@ -423,65 +423,45 @@ __global__ __launch_bounds__(64 * kRankWaves) void rank_sort_kernel(const uint64
 // bits 32..62 all but a few hundred of a million uniform bodies are already in their final place,
 // and the others form short RUNS of equal high bits (in source-index order, the passes being
 // stable) that only need sorting among themselves by the low bits.  That replaces the four low
-// passes (12 launches) by two: runs_mark_kernel lists the runs, runs_sort_kernel sorts each in
+// passes (12 launches) by one: runs_fix_kernel finds the runs and sorts each in
 // place -- a wave per run of <= 64 bodies (rank by counting, keys exchanged by shuffles), a
 // workgroup per longer run (counting against the whole run, out of place into the idle ping-pong
 // buffer, then copied back).  Any input is sorted correctly; a dense cluster just costs O(L^2)
 // compares for a run of L.  The result is the stable full-key order, bit for bit the 8-pass sort's.
 constexpr uint32_t kRunWave = 64;
 
-constexpr uint32_t kRunMarkItems = 4;  // bodies per thread: one returning global atomic per 1,024 bodies and list
+constexpr uint32_t kRunItems = 1;  // positions per thread: a workgroup looks at 256 consecutive positions
 
-__global__ __launch_bounds__(256) void runs_mark_kernel(const uint64_t *__restrict__ keys, uint32_t n,
-                                                        uint32_t low_bits, uint32_t *__restrict__ short_list,
-                                                        uint32_t *__restrict__ long_list,
-                                                        uint32_t *__restrict__ counts) {
-    // (returning atomics on one word serialise at ~7 ns each: one per workgroup and list, and a
-    // workgroup looks at 1,024 bodies -- at one per 256 bodies a clustered input, where most
-    // workgroups see a run, paid 30 us for them at 2^20 bodies; 4,096 bodies per workgroup are too
-    // few workgroups, 12 us)
-    __shared__ uint32_t s_n[2], s_base[2];
+// One launch (it was two -- a kernel listing the runs with aggregated atomics, a kernel sorting them -- and
+// the lists needed no more than LDS): a workgroup finds the runs that START among its 256 positions and
+// sorts them, short ones (< 64 bodies) a wave each, longer ones one after the other with all its threads.
+// (A neighbouring workgroup may still be looking for its run starts while this one already permutes a run:
+// it only ever compares the HIGH bits of a key, which a permutation inside a run does not change at any
+// position, and an aligned 64-bit load sees one key or the other.)
+__global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                       uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
+                                                       uint32_t n, uint32_t low_bits) {
+    __shared__ uint32_t s_short[256 * kRunItems], s_long[256 * kRunItems / kRunWave + 1], s_n[2];
     if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
     __syncthreads();
-    uint32_t kinds = 0, local[kRunMarkItems];  // 2 bits per item: 0 none, 1 first of a short run, 2 of a long run
 #pragma unroll
-    for (uint32_t c = 0; c < kRunMarkItems; ++c) {
-        const uint32_t k = (blockIdx.x * kRunMarkItems + c) * 256u + threadIdx.x;
-        uint32_t kind = 0;
+    for (uint32_t c = 0; c < kRunItems; ++c) {
+        const uint32_t k = (blockIdx.x * kRunItems + c) * 256u + threadIdx.x;
         if (k + 1u < n) {
             const uint64_t hi = keys[k] >> low_bits;
             const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
-            if (first && (keys[k + 1u] >> low_bits) == hi)
+            if (first && (keys[k + 1u] >> low_bits) == hi) {
                 // sorted by the high bits: if the body 64 places on still shares them, so do all in between
-                kind = (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) ? 2u : 1u;
+                if (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) s_long[atomicAdd(&s_n[1], 1u)] = k;
+                else s_short[atomicAdd(&s_n[0], 1u)] = k;
+            }
         }
-        local[c] = kind ? atomicAdd(&s_n[kind - 1u], 1u) : 0u;
-        kinds |= kind << (2u * c);
     }
     __syncthreads();
-    if (threadIdx.x < 2u && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_n[threadIdx.x]);
-    __syncthreads();
-    if (kinds == 0u) return;
-#pragma unroll
-    for (uint32_t c = 0; c < kRunMarkItems; ++c) {
-        const uint32_t k = (blockIdx.x * kRunMarkItems + c) * 256u + threadIdx.x;
-        const uint32_t kind = (kinds >> (2u * c)) & 3u;
-        if (kind == 1u) short_list[s_base[0] + local[c]] = k;
-        if (kind == 2u) long_list[s_base[1] + local[c]] = k;
-    }
-}
-
-__global__ __launch_bounds__(256) void runs_sort_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                        uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
-                                                        uint32_t n, uint32_t low_bits,
-                                                        const uint32_t *__restrict__ short_list,
-                                                        const uint32_t *__restrict__ long_list,
-                                                        const uint32_t *__restrict__ counts) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_short = counts[0], n_long = counts[1];
-    // short runs: one wave each
-    for (uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6); r < n_short; r += gridDim.x * 4u) {
-        const uint32_t start = short_list[r];
+    const uint32_t lane = threadIdx.x & 63u, n_short = s_n[0], n_long = s_n[1];
+    // short runs: one wave each (the order in which the lists were filled does not matter: the runs are disjoint)
+    for (uint32_t r = threadIdx.x >> 6; r < n_short; r += 4u) {
+        const uint32_t start = s_short[r];
         const uint64_t hi = keys[start] >> low_bits;
         const uint32_t pos = start + lane;
         const bool in = pos < n && (keys[min(pos, n - 1u)] >> low_bits) == hi;   // (a run is < 64 long here)
@@ -500,9 +480,9 @@ __global__ __launch_bounds__(256) void runs_sort_kernel(uint64_t *__restrict__ k
             vals[start + rank] = vi;
         }
     }
-    // long runs: one workgroup each
-    for (uint32_t r = blockIdx.x; r < n_long; r += gridDim.x) {
-        const uint32_t start = long_list[r];
+    // long runs: the whole workgroup, one after the other
+    for (uint32_t r = 0; r < n_long; ++r) {
+        const uint32_t start = s_long[r];
         const uint64_t hi = keys[start] >> low_bits;
         uint32_t lo_s = start + kRunWave, hi_s = n;   // first position past the run: binary search
         while (lo_s < hi_s) {
@@ -710,8 +690,7 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
 __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__ tile_u32,
                                                          Moments *__restrict__ tile_mom, uint32_t ntiles,
                                                          uint32_t stride, uint32_t *__restrict__ row_total,
-                                                         uint32_t *__restrict__ bound_slots,
-                                                         uint32_t *__restrict__ run_counts) {
+                                                         uint32_t *__restrict__ bound_slots) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (blockIdx.x < kCellRows) {
         // the row in chunks of 4,096 tiles: a wave 256 of them, every lane 4 consecutive tiles (one 16-byte
@@ -750,10 +729,7 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
         return;
     }
     const uint32_t comp = blockIdx.x - kCellRows;  // 0..3: m x, m y, m z, m -- a workgroup per component
-    if (comp == 0u) {
-        if (threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
-        if (threadIdx.x < 2u) run_counts[threadIdx.x] = 0u;           // the next step's sort fix-up lists
-    }
+    if (comp == 0u && threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
     {   // the moments, by the 1,024 threads in a fixed order: thread t sums the tiles [t S, (t+1) S) in
         // order, the threads' sums are scanned by wave (fixed shuffle tree) and the waves' totals
         // added in wave order -- deterministic whatever the launch timing
@@ -2189,8 +2165,6 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&d_aos, sizeof(nb_particle) * nn)) return rc;
         if (int rc = alloc(&hist, sizeof(uint32_t) * kSortMaxBins * (size_t)sort_blocks)) return rc;
         if (int rc = alloc(&totals, sizeof(uint32_t) * kSortMaxBins)) return rc;
-        if (int rc = alloc(&run_short, sizeof(uint32_t) * (nn / 2 + 2))) return rc;
-        if (int rc = alloc(&run_long, sizeof(uint32_t) * (nn / kRunWave + 2))) return rc;
         if (int rc = alloc(&cpl, nn + 2)) return rc;
         if (int rc = alloc(&int_slot, sizeof(uint32_t) * nn)) return rc;
         if (int rc = alloc(&tile_u32, sizeof(uint32_t) * kCellRows * ((size_t)cell_tiles + 4))) return rc;
@@ -2681,14 +2655,9 @@ class TreeSim final : public SimBase {
 #undef NB_PASS
                 kb ^= 1;
             }
-            if (shift0) {
-                uint32_t *run_counts = scalars + 12;  // zeroed by the previous step's cells_scan_kernel
-                hipLaunchKernelGGL(runs_mark_kernel, dim3((n + 256u * kRunMarkItems - 1u) / (256u * kRunMarkItems)), b256,
-                                   0, stream, keys[kb], n, shift0, run_short,
-                                   run_long, run_counts);
-                hipLaunchKernelGGL(runs_sort_kernel, dim3(1024), b256, 0, stream, keys[kb], idx[kb], keys[kb ^ 1],
-                                   idx[kb ^ 1], n, shift0, run_short, run_long, run_counts);
-            }
+            if (shift0)
+                hipLaunchKernelGGL(runs_fix_kernel, dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256, 0, stream,
+                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0);
         }
         uint64_t *skeys = keys[kb];
         order = idx[kb];
@@ -2705,7 +2674,7 @@ class TreeSim final : public SimBase {
                            tile_u32, tile_mom, cstride, rounds, status);
         uint32_t *row_total = scalars + 40;  // kCellRows words
         hipLaunchKernelGGL(cells_scan_kernel, dim3(kCellRows + 4), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
-                           row_total, bound_slots, scalars + 12);
+                           row_total, bound_slots);
         hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
                            depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
                            rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
@@ -3164,7 +3133,7 @@ class TreeSim final : public SimBase {
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1, sort_wide = 0;
-    uint32_t *tile_u32 = nullptr, *run_short = nullptr, *run_long = nullptr;
+    uint32_t *tile_u32 = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
     Moments *tile_mom = nullptr;
