@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t *__restrict__ hi
     if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
 }
 
-// exclusive scan over the workgroup of one value per thread (256 threads)
-__device__ __forceinline__ uint32_t sort_scan_256(uint32_t v, uint32_t *s_w) {
+// exclusive scan over the workgroup of one value per thread
+__device__ __forceinline__ uint32_t sort_scan_block(uint32_t v, uint32_t *s_w) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t x = v;
     for (int o = 1; o < 64; o <<= 1) {
@@ -232,19 +232,21 @@ __device__ __forceinline__ uint32_t sort_scan_256(uint32_t v, uint32_t *s_w) {
 // SCAN_INLINE (few tiles: the launch-bound small problems): `hist` holds the raw per-tile counts
 // and every block sums its digit rows itself -- thread t adds up its rows -- which saves the
 // bin_scan launch of the pass.  Thread t looks after the digits [t PER, (t + 1) PER).
-template <int W, uint32_t ITEMS, bool SCAN_INLINE>
-__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
+// THREADS x ITEMS elements = a sort tile (2,048-element tiles run as 512 threads x 4: twice the waves per SIMD
+// of 256 x 8 for a kernel that is a chain of LDS round trips and barriers).
+template <int W, uint32_t THREADS, uint32_t ITEMS, bool SCAN_INLINE>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals, uint32_t nblocks) {
-    constexpr uint32_t NB = 1u << W, PER = (NB + kSortThreads - 1u) / kSortThreads, TILE = kSortThreads * ITEMS;
-    __shared__ uint32_t s_cnt[4][NB];  // per-wave running digit counts -> exclusive wave offsets
+    constexpr uint32_t NB = 1u << W, PER = (NB + THREADS - 1u) / THREADS, TILE = THREADS * ITEMS, NWV = THREADS / 64u;
+    __shared__ uint32_t s_cnt[NWV][NB];  // per-wave running digit counts -> exclusive wave offsets
     __shared__ uint32_t s_base[NB];    // global start of each digit + this block's offset in it
-    __shared__ uint32_t s_tile[NB], s_w[4];
+    __shared__ uint32_t s_tile[NB], s_w[NWV];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t b0 = threadIdx.x * PER;  // my digits: b0 .. b0 + PER - 1 (none if b0 >= NB)
-    for (uint32_t w = 0; w < 4; ++w)
-        for (uint32_t b = threadIdx.x; b < NB; b += kSortThreads) s_cnt[w][b] = 0;
+    for (uint32_t w = 0; w < NWV; ++w)
+        for (uint32_t b = threadIdx.x; b < NB; b += THREADS) s_cnt[w][b] = 0;
     {   // exclusive scan of the digit totals (tiny; every block redoes it)
         uint32_t t[PER], mine[PER], sum = 0;  // digit total over all tiles; the tiles before this one
 #pragma unroll
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             }
             sum += t[q];
         }
-        uint32_t run = sort_scan_256(sum, s_w);
+        uint32_t run = sort_scan_block(sum, s_w);
 #pragma unroll
         for (uint32_t q = 0; q < PER; ++q) {
             if (b0 + q < NB) s_base[b0 + q] = run + mine[q];
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
         local[c] = before + rank;
     }
     __syncthreads();
-    {   // per digit: exclusive prefix over the 4 waves and the digit's count in this tile; then the
+    {   // per digit: exclusive prefix over the waves and the digit's count in this tile; then the
         // exclusive scan of the tile's digit counts: where each digit's run starts inside the tile
         uint32_t cnt[PER], sum = 0;
 #pragma unroll
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             cnt[q] = 0;
             if (b0 + q < NB) {
                 uint32_t o = 0;
-                for (uint32_t w = 0; w < 4; ++w) {
+                for (uint32_t w = 0; w < NWV; ++w) {
                     const uint32_t t = s_cnt[w][b0 + q];
                     s_cnt[w][b0 + q] = o;
                     o += t;
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
             }
             sum += cnt[q];
         }
-        uint32_t run = sort_scan_256(sum, s_w);
+        uint32_t run = sort_scan_block(sum, s_w);
 #pragma unroll
         for (uint32_t q = 0; q < PER; ++q) {
             if (b0 + q < NB) s_tile[b0 + q] = run;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint32_t tile_n = min(TILE, n - blockIdx.x * TILE);
 #pragma unroll
     for (uint32_t c = 0; c < ITEMS; ++c) {
-        const uint32_t j = c * kSortThreads + threadIdx.x;
+        const uint32_t j = c * THREADS + threadIdx.x;
         if (j < tile_n) {
             const uint64_t k = s_key[j];
             const uint32_t d = (uint32_t)(k >> shift) & (NB - 1u);
@@ -2631,18 +2633,18 @@ class TreeSim final : public SimBase {
                 const bool inl = sort_blocks <= kSortInlineScanBlocks;
 #define NB_PASS(WW, ITEMS)                                                                                          \
     do {                                                                                                            \
+        constexpr uint32_t TH = (ITEMS) == kSortItems ? 2u * kSortThreads : kSortThreads; /* scatter's threads */    \
+        constexpr uint32_t IT = kSortThreads * (ITEMS) / TH;                              /* ... and items */        \
         if (ps != 0u)                                                                                               \
             hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(sort_blocks), dim3(kSortThreads), 0, stream,        \
                                keys[kb], n, shift, bins, hist, sort_blocks);                                        \
         if (inl) {                                                                                                  \
-            hipLaunchKernelGGL((radix_scatter_kernel<WW, ITEMS, true>), dim3(sort_blocks),                          \
-                               dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
-                               shift, hist, totals, sort_blocks);                                                   \
+            hipLaunchKernelGGL((radix_scatter_kernel<WW, TH, IT, true>), dim3(sort_blocks), dim3(TH), 0, stream,    \
+                               keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals, sort_blocks);  \
         } else {                                                                                                    \
             hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);            \
-            hipLaunchKernelGGL((radix_scatter_kernel<WW, ITEMS, false>), dim3(sort_blocks),                         \
-                               dim3(kSortThreads), 0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n,      \
-                               shift, hist, totals, sort_blocks);                                                   \
+            hipLaunchKernelGGL((radix_scatter_kernel<WW, TH, IT, false>), dim3(sort_blocks), dim3(TH), 0, stream,   \
+                               keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals, sort_blocks);  \
         }                                                                                                           \
     } while (0)
                 if (W == kSortWideBits) {
