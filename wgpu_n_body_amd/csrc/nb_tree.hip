@@ -2633,7 +2633,7 @@ class TreeSim final : public SimBase {
                 const bool inl = sort_blocks <= kSortInlineScanBlocks;
 #define NB_PASS(WW, ITEMS)                                                                                          \
     do {                                                                                                            \
-        constexpr uint32_t TH = (ITEMS) == kSortItems ? 2u * kSortThreads : kSortThreads; /* scatter's threads */    \
+        constexpr uint32_t TH = 2u * kSortThreads;                                        /* scatter's threads */    \
         constexpr uint32_t IT = kSortThreads * (ITEMS) / TH;                              /* ... and items */        \
         if (ps != 0u)                                                                                               \
             hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(sort_blocks), dim3(kSortThreads), 0, stream,        \
