@@ -164,22 +164,23 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
 // (Counting the tile histograms of digit p + 1 inside the scatter of pass p, with one global atomic
 // per element where it lands, was measured and dropped: 47 instead of 12 us per scatter at 2^20
 // bodies, 10.8 instead of 5 + 5 at 8,192 -- profiles/r02_sort_experiments.txt.)
+// (ITEMS elements per thread of a 2 x kSortThreads workgroup: the tile of the scatter, whatever its order inside)
 template <uint32_t ITEMS>
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(
+__global__ __launch_bounds__(2 * kSortThreads) void radix_hist_kernel(
     const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins, uint32_t *__restrict__ hist,
     uint32_t nblocks) {
+    constexpr uint32_t THREADS = 2u * kSortThreads;
     __shared__ uint32_t s_hist[kSortMaxBins];
-    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += kSortThreads) s_hist[b] = 0;
+    for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += THREADS) s_hist[b] = 0;
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t base = blockIdx.x * (kSortThreads * ITEMS) + wave * (64 * ITEMS);
+    const uint32_t base = blockIdx.x * (THREADS * ITEMS) + threadIdx.x;
 #pragma unroll
     for (uint32_t c = 0; c < ITEMS; ++c) {
-        const uint32_t i = base + c * 64 + lane;
+        const uint32_t i = base + c * THREADS;
         if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & (bins - 1u)], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bins; b += kSortThreads) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
+    for (uint32_t b = threadIdx.x; b < bins; b += THREADS) hist[b * nblocks + blockIdx.x] = s_hist[b];  // bin-major
 }
 
 // One workgroup per bin: exclusive scan of that bin's per-block counts; the bin total goes to
@@ -2636,7 +2637,7 @@ class TreeSim final : public SimBase {
         constexpr uint32_t TH = 2u * kSortThreads;                                        /* scatter's threads */    \
         constexpr uint32_t IT = kSortThreads * (ITEMS) / TH;                              /* ... and items */        \
         if (ps != 0u)                                                                                               \
-            hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(sort_blocks), dim3(kSortThreads), 0, stream,        \
+            hipLaunchKernelGGL((radix_hist_kernel<IT>), dim3(sort_blocks), dim3(TH), 0, stream,                     \
                                keys[kb], n, shift, bins, hist, sort_blocks);                                        \
         if (inl) {                                                                                                  \
             hipLaunchKernelGGL((radix_scatter_kernel<WW, TH, IT, true>), dim3(sort_blocks), dim3(TH), 0, stream,    \
