@@ -635,10 +635,11 @@ __device__ __forceinline__ Moments block_scan_moments(Moments v, Moments *s_wave
 // Round 1 ran this as thirteen small kernels (gather, cpl, three scans of the opened-cell counts,
 // depth histogram + scan + bases, ids, two moment passes + scan); it is one prefix computation
 // over the sorted bodies with a 28-word state: 1 count of opened cells, 23 per-depth node counts,
-// 4 binary64 moments.  A: per tile of 1,024 bodies, gather + cpl + the tile's totals.  B: ONE
-// workgroup scans the tiles' totals (fixed order: deterministic moments) and derives the depth
-// bases and the node count.  C: per tile, the bodies' own prefixes inside the tile + the tile's
-// offsets -> node ids, slots and moment prefixes.  Any number of tiles: no size cap.
+// 4 binary64 moments.  A: per tile of 1,024 bodies, gather + cpl + the tile's totals.  B: the
+// tiles' totals scanned, a workgroup per table row and per moment component (fixed order:
+// deterministic moments).  C: the depth bases and the node count from the rows' totals, then per
+// tile the bodies' own prefixes inside the tile + the tile's offsets -> node ids, slots and moment
+// prefixes.  Any number of tiles: no size cap.
 constexpr uint32_t kCellTile = 1024;                 // bodies per workgroup of A and C: 4 rounds of 256 (1 round
                                                      // = 256 bodies on small problems, which are bound by the
                                                      // chain of barriers inside a workgroup, not by work)
