@@ -23,4 +23,6 @@ for n in 8192 16384 131072 1048576; do bash tools/trace_tree.sh r02_$n --bodies 
 ./wgpu_n_body_amd/headless > $O/headless_cli.txt 2>&1
 ./wgpu_n_body_amd/headless --sim naive --n 65536 --steps 5 --devices 0,0,0,0,0,0,0,0 >> $O/headless_cli.txt 2>&1
 python tools/host_overhead.py > $O/host_overhead.txt 2>&1 || true
+python tools/bench_tree_let.py --bodies 4194304 > $O/tree_let_per_rank.json 2> $O/tree_let.err || true
+for n in 65536 262144 1048576 4194304; do python tools/let_export_latency.py $n 8 | grep "^n "; done > $O/let_export.txt 2>&1 || true
 echo "all done"; ls $O

@@ -19,5 +19,12 @@ for n in 8192 16384 131072 1048576; do
   cat $O/trace_$n.txt >> profiles/${TAG}_step_timelines.txt
 done
 cp $O/headless_cli.txt profiles/${TAG}_headless_cli.txt
+if [ -s $O/tree_let_per_rank.json ]; then grep '^{' $O/tree_let_per_rank.json | tail -1 > profiles/${TAG}_tree_let_per_rank.json; fi
+if [ -s $O/let_export.txt ]; then
+  { echo "# tools/let_export_latency.py: NB_PHASE_LET_BUILD (octree of the rank's bodies + LET export for 7 peers) of ONE rank"
+    echo "# with the GPU to itself, 8 Morton domains of a uniform cube, theta 0.5.  Export mode 0: a launch per tree level"
+    echo "# (23 dependent launches), mode 1: one launch, a workgroup per peer and root grandchild (default)."
+    cat $O/let_export.txt; } > profiles/${TAG}_let_export.txt
+fi
 grep -v "amdgpu.ids\|c10d\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/host_overhead.txt > profiles/${TAG}_host_overhead.txt
 git status --short profiles | head -20
