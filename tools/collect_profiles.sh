@@ -13,7 +13,7 @@ bash tools/profile_tree_hbm.sh r02 > $O/tree_hbm_traffic.txt 2>&1 || { tail $O/t
 bash tools/profile_tree_pmc.sh r02 > $O/tree_walk_sq_counters.txt 2>&1 || { tail $O/tree_walk_sq_counters.txt; exit 1; }
 echo "profiles done"
 python tools/criterion_sizes.py > $O/criterion.txt 2>&1 && cp gpurun_out/criterion_sizes.json $O/criterion_sizes.json
-for cfg in "" "--theta 0.75" "--bodies 4194304" "--bodies 4000000 --theta 0.75 --seed 0" "--bodies 16777216 --theta 0.75 --steps 10" "--bodies 100000 --theta 0.75 --init disc --g 0.00001 --dt 0.0016" "--mode 0"; do
+for cfg in "" "--theta 0.75" "--bodies 4194304" "--bodies 4000000 --theta 0.75 --seed 0" "--bodies 16777216 --theta 0.75 --steps 10" "--bodies 26843545 --theta 0.75 --steps 5" "--bodies 100000 --theta 0.75 --init disc --g 0.00001 --dt 0.0016" "--mode 0"; do
   echo "# bench_tree.py $cfg" >> $O/tree_bench.txt
   python tools/bench_tree.py $cfg --warmup 30 >> $O/tree_bench.txt 2>&1 || { tail -5 $O/tree_bench.txt; exit 1; }
 done
