@@ -67,8 +67,13 @@ def check_against_oracles(out, ref32, ref64, steps):
 
 
 def test_gpu_present_and_library_is_the_hip_one(gpu):
+    """... and it is the library built from THESE sources: libnbody_hip.so is git-ignored and travels to
+    the GPU box as a binary, so the box has to prove which one it loaded (nb_version() ends with a hash
+    of the sources it was compiled from; tests/test_abi.py checks the same thing without a GPU)."""
+    from wgpu_n_body_amd.build import source_hash
     assert gpu.device_count() >= 1
     assert "gfx950" in gpu.version()
+    assert gpu.version().endswith("src:" + source_hash()), (gpu.version(), source_hash())
 
 
 def test_kat1_two_bodies(gpu, oracle):

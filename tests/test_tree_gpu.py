@@ -368,6 +368,36 @@ def test_many_fresh_tree_sims_are_consistent(gpu):
         s.destroy()
 
 
+def test_graph_captured_after_an_eager_step_survives_a_new_state(gpu):
+    """A hipGraph captured after an eager step takes the root cube from the slots the previous walk
+    filled and holds no bound_kernel.  nb_sim_write_particles (snapshot resume, re-init) must drop it:
+    replayed on a state 7.5x as wide it would key every body in the old cube.  Against a fresh
+    simulator on the same state, bit for bit."""
+    nb = gpu
+    n = 20000
+    sp = nb.SimParams(particle_num=n)
+    first = nb.inits.uniform_init(sp, seed=41)
+    wide = nb.as_floats(nb.inits.uniform_init(sp, seed=42)).copy()
+    wide[:, 0:3] *= np.float32(7.5)
+    sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), first)
+    sim.encode(); sim.wait()                       # eager: the walk leaves the next root cube
+    sim.set_tuning("tree_use_graph", 1)
+    sim.encode(); sim.wait()                       # captured without bound_kernel
+    sim.write_particles(wide)
+    sim.encode(); sim.encode(); sim.wait()
+    got = sim.dest_particle_slice().copy()
+    _, rw = sim.read_tree()
+    assert not sim.debug_buffer("status", np.uint32).any()
+    sim.destroy()
+    ref = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.5), wide)
+    ref.encode(); ref.encode(); ref.wait()
+    want = ref.dest_particle_slice().copy()
+    _, rw_ref = ref.read_tree()
+    ref.destroy()
+    assert rw == rw_ref and rw > 7.0
+    assert np.array_equal(got, want)
+
+
 def test_clustered_input_cannot_overflow_the_build(gpu):
     """Pairs of nearly coincident bodies open ~20 single-child cells each: far more internal
     cells than the reference's 4N-node capacity (tree.rs:188-190, where the reference panics).
@@ -457,6 +487,103 @@ def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
     assert np.array_equal(np.sort(a["order"]), np.arange(n, dtype=np.uint32))
     assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
     assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
+
+
+def test_visualize_workload_at_its_own_size_against_oracle(gpu, oracle):
+    """the workload of src/bin/visualize.rs:26-38 at its own size -- 100,000 bodies of
+    `disc_init` (a 150,000-mass body at the origin, mass contrast 1.5e5 : 1, a thin and deep tree),
+    g = 1e-5, dt = 0.0016, theta = 0.75 -- against the oracle's restatement of the reference's builder and
+    per-thread walk: tree, numbering and body order bit for bit, every body's new position bit for bit,
+    forces to the tolerances of check_step (on all bodies and, separately, on the windows where the disc
+    is hardest: around the central mass, mid-disc, at the rim), visit / accept totals.  Recorded, not
+    required: the deepest the reference's 64-entry stack (tree.wgsl:44-45) would have gone on this input."""
+    n, g, dt, theta = 100000, 0.00001, 0.0016, 0.75
+    s = make_state("disc", n, 26, g)
+    ref = oracle.tree_step_f32(s, g, E, dt, theta, flags=oracle.INTENDED)
+    r = run_tree(gpu, s, theta, 1, g, E, dt)
+    assert not r["status"].any()
+    check_tree(r["tree"], r["root_width"], r["order"], ref["tree"], ref["root_width"], ref["order"])
+    check_step(r["dst"], ref["dst"])
+    pos0 = int(np.nonzero(ref["order"] == 0)[0][0])                       # the central mass, in sorted order
+    rim = int(np.hypot(ref["sorted_src"][:, 0], ref["sorted_src"][:, 1]).argmax())
+    for centre in (pos0, n // 2, rim):
+        lo = min(max(centre - 128, 0), n - 256)
+        check_step(r["dst"][lo:lo + 256], ref["dst"][lo:lo + 256])
+    assert abs(int(r["counters"][0]) - ref["stats"]["visits"]) <= max(2, 1e-5 * ref["stats"]["visits"])
+    assert abs(int(r["counters"][1]) - ref["stats"]["accepted"]) <= max(2, 1e-5 * ref["stats"]["accepted"])
+    # the reference's fixed stack: 36 of its 64 entries on this input (seed 26) -- it does not overflow here
+    assert ref["stats"]["overflowed"] == 0 and ref["stats"]["high_water"] <= 64, ref["stats"]
+    print(f"disc 100,000: {len(ref['tree'])} nodes, oracle stack high water {ref['stats']['high_water']} of 64, "
+          f"{ref['stats']['visits'] / n:.0f} visits per body")
+
+
+def test_visualize_workload_over_fifty_steps(gpu, oracle):
+    """... and over time.  (a) 100,000 bodies, 50 steps: finite, no status word raised (node capacity, key
+    collisions, stack guard).  (b) A 4,096-body disc with the same parameters, 50 Barnes-Hut steps
+    against 50 binary64 all-pairs steps of the oracle (naive.wgsl's force law): the
+    disc is not in equilibrium (its kinetic energy grows 14 % over the 50 steps), so what is compared is
+    the energy reached and the angular momentum kept -- both to 2e-3, Barnes-Hut's own error at
+    theta = 0.75 (measured: see DESIGN.md section 6)."""
+    nb = gpu
+    g, dt, theta = 0.00001, 0.0016, 0.75
+    big = run_tree(nb, make_state("disc", 100000, 26, g), theta, 50, g, E, dt, count=False)
+    assert np.isfinite(big["dst"]).all() and not big["status"].any()
+    s = make_state("disc", 4096, 27, g)
+    got = run_tree(nb, s, theta, 50, g, E, dt, count=False)
+    assert np.isfinite(got["dst"]).all() and not got["status"].any()
+    ref = oracle.naive_run_f64(s, g, E, dt, 50)
+    f8 = lambda a: a.astype(np.float64)
+    ke = lambda a: (0.5 * f8(a[:, 9]) * (f8(a[:, 3:6]) ** 2).sum(1)).sum()
+    lz = lambda a: (f8(a[:, 9]) * (f8(a[:, 0]) * f8(a[:, 4]) - f8(a[:, 1]) * f8(a[:, 3]))).sum()
+    d_ke = abs(ke(got["dst"]) - ke(ref)) / ke(ref)
+    d_lz = abs(lz(got["dst"]) - lz(ref)) / abs(lz(ref))
+    print(f"disc 4,096 x 50 steps: kinetic energy {ke(s):.4f} -> {ke(got['dst']):.4f} (all-pairs fp64 {ke(ref):.4f}, "
+          f"rel diff {d_ke:.2e}); L_z rel diff {d_lz:.2e}")
+    assert d_ke < 2e-3 and d_lz < 2e-3, (d_ke, d_lz)
+
+
+@pytest.mark.gpu
+def test_dense_core_does_not_stall_the_sort(gpu):
+    """The normal late state of a gravitational run: a dense core plus a few far escapers that set the root
+    cube.  The core then fills a handful of the cells the high-digit passes can tell apart, the fix-up
+    meets runs of 10^4 .. 10^6 bodies that tie there, and ranking such a run by counting (L^2 compares
+    in one workgroup) would take seconds to minutes.  Runs longer than 1,024 are radix-sorted by the
+    workgroup instead, and the statistics the fix-up leaves make the next builds sort more high digits
+    (TreeSim::adapt_sort).  Must hold: the same order / tree / state as the 8-pass full sort, bit for
+    bit, on every step; a first step in well under a second; later steps at the usual speed."""
+    import time
+    nb = gpu
+    n = 1 << 20
+    rng = np.random.default_rng(2025)    # (a seed without two bodies in one 2^-21 cell)
+    state = np.zeros((n, 10), dtype=np.float32)
+    core = int(0.9 * n)
+    state[:core, 0:3] = rng.uniform(-0.006, 0.006, size=(core, 3)).astype(np.float32) + np.float32(0.3)
+    state[core:, 0:3] = rng.uniform(-1.0, 1.0, size=(n - core, 3)).astype(np.float32)
+    state[:, 9] = 1.0
+    state = state[rng.permutation(n)]
+    sp = nb.SimParams(particle_num=n, g=1e-9)          # (weak coupling: the core must not collapse within the test)
+    sims = {}
+    for mode in (1, 0):
+        sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(0.75), state)
+        sim.set_tuning("tree_sort_mode", mode)
+        sims[mode] = sim
+    times = []
+    for step in range(5):
+        outs = {}
+        for mode, sim in sims.items():
+            t0 = time.perf_counter()
+            sim.encode()
+            sim.wait()
+            if mode == 1:
+                times.append(time.perf_counter() - t0)
+            outs[mode] = (sim.debug_buffer("order", np.uint32).copy(), sim.dest_particle_slice().copy())
+        assert np.array_equal(outs[0][0], outs[1][0]), step
+        assert np.array_equal(outs[0][1], outs[1][1]), step
+    assert not sims[1].debug_buffer("status", np.uint32).any()
+    for sim in sims.values():
+        sim.destroy()
+    assert times[0] < 0.5, times        # the step that meets the long runs unprepared
+    assert max(times[2:]) < 0.02, times  # once the passes cover them: a few ms (the walk of a dense core)
 
 
 @pytest.mark.gpu

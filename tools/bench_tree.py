@@ -91,4 +91,4 @@ print(json.dumps({
     "lane_visits_per_s": float(c0[0]) / (walk * 1e-3),
     "cells_per_wave_step1": float(c0[2]) / ((args.bodies + 63) // 64), "stack_high_water": int(c0[3]), "leaf_fraction_of_wave_cells": float(c0[4]) / float(c0[2]) if c0[2] else None,
     "lane_utilisation": (float(c0[0]) / float(c0[7]) if c0[7] else float(c0[0]) / (64.0 * float(c0[2]))) if c0[2] else None,
-    "batches_step1": int(c0[6]), "mode": args.mode, "group": args.group, "steps": args.steps, "warmup": args.warmup, "cpu_baseline": cpu}))
+    "batches_step1": int(c0[6]), "evaluated_batches_step1": int(c0[9]), "idle_pair_slots_step1": int(c0[8]), "mode": args.mode, "group": args.group, "steps": args.steps, "warmup": args.warmup, "cpu_baseline": cpu}))

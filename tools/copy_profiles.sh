@@ -1,12 +1,20 @@
 #!/bin/bash
-# Copies what tools/collect_profiles.sh left under gpurun_out/ into the committed profiles/<tag>_* files.
+# Copies what tools/collect_profiles.sh <tag> left under gpurun_out/ into the committed profiles/<tag>_* files.
+# Fails -- before copying anything -- if an artefact is missing or empty.
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/${TAG}final
+STATS="$(find gpurun_out/prof_tree_$TAG/trace -name '*kernel_stats.csv' | head -1)"
+for f in $O/bench_n1.json "$STATS" $O/tree_hbm_traffic.txt $O/tree_walk_sq_counters.txt $O/criterion.txt \
+         $O/criterion_sizes.json $O/tree_bench.txt $O/tree_bench_cpu_baseline.json $O/headless_cli.txt \
+         $O/trace_8192.txt $O/trace_16384.txt $O/trace_131072.txt $O/trace_1048576.txt; do
+  [ -s "$f" ] || { echo "copy_profiles: '$f' is missing or empty -- nothing copied"; exit 1; }
+done
+grep -q "SQ_INSTS_VALU" $O/tree_walk_sq_counters.txt || { echo "copy_profiles: no SQ counters of the walk -- nothing copied"; exit 1; }
 python tools/summarize_profile.py $TAG > /dev/null
 tail -1 $O/bench_n1.json > profiles/${TAG}_bench_n1.json
-cp "$(find gpurun_out/prof_tree_$TAG/trace -name '*kernel_stats.csv' | head -1)" profiles/${TAG}_tree_kernel_stats.csv
+cp "$STATS" profiles/${TAG}_tree_kernel_stats.csv
 cp $O/tree_hbm_traffic.txt profiles/${TAG}_tree_hbm_traffic.txt
 cp $O/tree_walk_sq_counters.txt profiles/${TAG}_tree_walk_sq_counters.txt
 cp $O/criterion.txt profiles/${TAG}_criterion_sizes.txt
@@ -26,5 +34,8 @@ if [ -s $O/let_export.txt ]; then
     echo "# (23 dependent launches), mode 1: one launch, a workgroup per peer and root grandchild (default)."
     cat $O/let_export.txt; } > profiles/${TAG}_let_export.txt
 fi
-grep -v "amdgpu.ids\|c10d\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/host_overhead.txt > profiles/${TAG}_host_overhead.txt
-git status --short profiles | head -20
+if [ -s $O/host_overhead.txt ]; then
+  grep -v "amdgpu.ids\|c10d\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/host_overhead.txt > profiles/${TAG}_host_overhead.txt
+fi
+for f in profiles/${TAG}_*; do [ -s "$f" ] || { echo "copy_profiles: $f came out empty"; exit 1; }; done
+git status --short profiles | head -30

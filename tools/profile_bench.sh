@@ -6,7 +6,7 @@
 # Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profile.py turns them into
 # profiles/<tag>_*.{txt,json}.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace of the Barnes-Hut step benchmark (run through gpurun).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_tree_$TAG
 mkdir -p $OUT

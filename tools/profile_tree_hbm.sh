@@ -4,7 +4,7 @@
 # Prints per-kernel averages per launch: KiB read (x2 = the gfx950 correction for wide reads),
 # KiB written, duration, and the achieved HBM GB/s.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_tree_hbm_$TAG
 rm -rf $OUT; mkdir -p $OUT

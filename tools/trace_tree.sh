@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of a few Barnes-Hut steps: per-kernel durations and the gaps between
 # consecutive kernels of one step (run through gpurun).  usage: trace_tree.sh TAG [bench_tree args]
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/trace_tree_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -434,6 +434,93 @@ __global__ __launch_bounds__(64 * kRankWaves) void rank_sort_kernel(const uint64
 constexpr uint32_t kRunWave = 64;
 
 constexpr uint32_t kRunItems = 1;  // positions per thread: a workgroup looks at 256 consecutive positions
+// A run longer than this is not ranked by counting (L^2 compares by one workgroup: a dense core of 10^5..10^6
+// bodies inside a root cube that a few escapers have stretched -- the normal late state of a gravitational
+// run -- would take seconds to minutes) but radix-sorted on its low bits by the workgroup: O(L) per digit.
+constexpr uint32_t kRunCountMax = 1024;
+// The host's part (TreeSim::wait): the longest run of a step comes back through the status words, and the
+// next steps sort one more high digit per kRunBoostAbove exceeded -- the fix-up then sees short runs again;
+// `probe` tells it when the extra digits can go.  Speed only: every path gives the stable full-key order.
+constexpr uint32_t kRunBoostAbove = 1024, kRunProbeSpan = 512;
+
+// The run [start, start + len) of keys that tie on their high bits, sorted in place by the low `low_bits`
+// bits, stably, by one workgroup of 256: LSD radix, 8 bits per pass, between the run's own slots in
+// (keys, vals) and in (alt_keys, alt_vals).  A pass = a histogram sweep, a scan of the 256 counts, and a
+// scatter sweep in chunks of 256 -- a thread per element, ranked among the chunk's equal digits by wave
+// ballots and per-wave counts (the scheme of radix_scatter_kernel).  Digits on which the whole run agrees
+// are skipped.
+__device__ void run_radix_sort(uint64_t *keys, uint32_t *vals, uint64_t *alt_keys, uint32_t *alt_vals, uint32_t start,
+                               uint32_t len, uint32_t low_bits, uint32_t *s_hist, uint32_t (*s_wcnt)[256], uint32_t *s_w,
+                               uint32_t *s_flag) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t *ks = keys + start, *kd = alt_keys + start;
+    uint32_t *vs = vals + start, *vd = alt_vals + start;
+    bool in_alt = false;
+    for (uint32_t sh = 0; sh < low_bits; sh += 8u) {
+        const uint32_t dmask = low_bits - sh >= 8u ? 255u : (1u << (low_bits - sh)) - 1u;
+        s_hist[tid] = 0u;
+        for (uint32_t w = 0; w < 4u; ++w) s_wcnt[w][tid] = 0u;
+        if (tid == 0u) *s_flag = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256u) atomicAdd(&s_hist[(uint32_t)(ks[i] >> sh) & dmask], 1u);
+        __syncthreads();
+        const uint32_t mine = s_hist[tid];
+        if (mine == len) *s_flag = 1u;  // every key of the run has this digit: nothing moves
+        const uint32_t base = sort_scan_block(mine, s_w);  // (syncs: s_flag is visible after it)
+        if (*s_flag) {
+            __syncthreads();
+            continue;
+        }
+        s_hist[tid] = base;  // from here on: where the next key with digit tid goes
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < len; c0 += 256u) {
+            const uint32_t i = c0 + tid;
+            const bool valid = i < len;
+            const uint64_t key = valid ? ks[i] : 0ull;
+            const uint32_t val = valid ? vs[i] : 0u;
+            const uint32_t d = (uint32_t)(key >> sh) & dmask;
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const uint64_t bal = __ballot((d >> bb) & 1u);
+                peers &= ((d >> bb) & 1u) ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && rank == 0u) s_wcnt[wave][d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (valid) {
+                uint32_t off = s_hist[d] + rank;
+                for (uint32_t w = 0; w < wave; ++w) off += s_wcnt[w][d];
+                kd[off] = key;
+                vd[off] = val;
+            }
+            __syncthreads();
+            {   // thread t looks after digit t: advance its base, clear the chunk's counts
+                uint32_t t = 0u;
+                for (uint32_t w = 0; w < 4u; ++w) {
+                    t += s_wcnt[w][tid];
+                    s_wcnt[w][tid] = 0u;
+                }
+                s_hist[tid] += t;
+            }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint64_t *tk = ks; ks = kd; kd = tk;
+        uint32_t *tv = vs; vs = vd; vd = tv;
+        in_alt = !in_alt;
+    }
+    if (in_alt) {  // an odd number of passes moved: the sorted run sits in the alternate buffers
+        for (uint32_t i = tid; i < len; i += 256u) {
+            kd[i] = ks[i];
+            vd[i] = vs[i];
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+}
 
 // One launch (it was two -- a kernel listing the runs with aggregated atomics, a kernel sorting them -- and
 // the lists needed no more than LDS): a workgroup finds the runs that START among its 256 positions and
@@ -441,26 +528,36 @@ constexpr uint32_t kRunItems = 1;  // positions per thread: a workgroup looks at
 // (A neighbouring workgroup may still be looking for its run starts while this one already permutes a run:
 // it only ever compares the HIGH bits of a key, which a permutation inside a run does not change at any
 // position, and an aligned 64-bit load sees one key or the other.)
+// stat[0]: the longest run met (atomicMax; the launch of the step before zeroed it: stat_clear = the word
+// of the other parity).  stat[2], with probe_bits != 0: set if some run of keys that tie on all but their low
+// probe_bits bits is longer than kRunProbeSpan -- what the fix-up would meet with one high digit less.
 __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                        uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
-                                                       uint32_t n, uint32_t low_bits) {
-    __shared__ uint32_t s_short[256 * kRunItems], s_long[256 * kRunItems / kRunWave + 1], s_n[2];
-    if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
+                                                       uint32_t n, uint32_t low_bits, uint32_t probe_bits,
+                                                       uint32_t *__restrict__ stat, uint32_t *__restrict__ stat_clear) {
+    __shared__ uint32_t s_short[256 * kRunItems], s_long[256 * kRunItems / kRunWave + 1], s_n[3];
+    __shared__ uint32_t s_hist[256], s_wcnt[4][256], s_w[4], s_flag;
+    if (threadIdx.x < 3u) s_n[threadIdx.x] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = 0u;
     __syncthreads();
 #pragma unroll
     for (uint32_t c = 0; c < kRunItems; ++c) {
         const uint32_t k = (blockIdx.x * kRunItems + c) * 256u + threadIdx.x;
         if (k + 1u < n) {
-            const uint64_t hi = keys[k] >> low_bits;
+            const uint64_t kk = keys[k];
+            const uint64_t hi = kk >> low_bits;
             const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
             if (first && (keys[k + 1u] >> low_bits) == hi) {
                 // sorted by the high bits: if the body 64 places on still shares them, so do all in between
                 if (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) s_long[atomicAdd(&s_n[1], 1u)] = k;
                 else s_short[atomicAdd(&s_n[0], 1u)] = k;
             }
+            if (probe_bits && k + kRunProbeSpan < n && (keys[k + kRunProbeSpan] >> probe_bits) == (kk >> probe_bits))
+                s_n[2] = 1u;
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0u && s_n[2]) atomicMax(&stat[2], 1u);
     const uint32_t lane = threadIdx.x & 63u, n_short = s_n[0], n_long = s_n[1];
     // short runs: one wave each (the order in which the lists were filled does not matter: the runs are disjoint)
     for (uint32_t r = threadIdx.x >> 6; r < n_short; r += 4u) {
@@ -493,6 +590,11 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ ke
             if ((keys[mid] >> low_bits) == hi) lo_s = mid + 1u; else hi_s = mid;
         }
         const uint32_t len = lo_s - start;
+        if (threadIdx.x == 0u) atomicMax(&stat[0], len);
+        if (len > kRunCountMax) {
+            run_radix_sort(keys, vals, alt_keys, alt_vals, start, len, low_bits, s_hist, s_wcnt, s_w, &s_flag);
+            continue;
+        }
         for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
             const uint64_t ki = keys[start + i];
             uint32_t rank = 0;
@@ -598,8 +700,11 @@ struct __attribute__((aligned(32))) NodeRec {
     float4 cogm;
     uint32_t first, count;  // children ids first .. first+count-1 (octant order); leaf: count 0
     uint32_t self_pos;      // leaf: sorted position of its body; cell: ~0 (matches no body)
-    float ssize2;           // cell: its squared size, root_width^2 / 4^depth (exact, tree.wgsl:82);
-                            // leaf: -1, which makes "size^2 < theta^2 r^2" always true
+    float mac2;             // cell: its squared ACCEPTANCE RADIUS, size^2 / theta^2 with size^2 = root_width^2 / 4^depth
+                            // (tree.wgsl:82; rounded once here, so that every test of the cell -- each body's own,
+                            // the group's all-open shortcut, a LET export's box test -- compares the same number
+                            // with its r^2: size/dist < theta (tree.wgsl:63-64) as mac2 < r^2);
+                            // leaf: -1, which makes the test always true
 };
 
 // ---- 6a. mass moments by prefix sums ------------------------------------------------------------
@@ -897,7 +1002,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const Moments *__restrict__ mom, const uint32_t *__restrict__ depth_base,
                             const uint32_t *__restrict__ bound_bits,
                             float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
-                            uint32_t *__restrict__ child, NodeRec *__restrict__ rec) {
+                            uint32_t *__restrict__ child, NodeRec *__restrict__ rec, float inv_theta2) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     if (id >= n_nodes) return;
@@ -1011,7 +1116,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             const float root_width = __uint_as_float(*bound_bits) * 2.0f;
             float size2 = root_width * root_width;
             for (uint32_t l = 0; l < d; ++l) size2 *= 0.25f;  // exact: the width halves per level
-            rec[id] = NodeRec{q, first, cnt, ~0u, size2};
+            rec[id] = NodeRec{q, first, cnt, ~0u, size2 * inv_theta2};
         }
     }
     if (AOS) {
@@ -1053,7 +1158,7 @@ struct WalkStats {
 // instead of branched around, and the lane sets are 64-bit masks combined by s_and/s_andn2.
 template <uint32_t K, bool COUNT>
 __device__ __forceinline__ void walk_cells(const NodeRec *__restrict__ rp, uint64_t gmask, uint32_t i,
-                                           float xi, float yi, float zi, float theta2, float e,
+                                           float xi, float yi, float zi, float e,
                                            float &ax, float &ay, float &az, StackEntry *stack,
                                            uint32_t &sp, bool lane0, WalkStats &st) {
     NodeRec r[K];
@@ -1064,9 +1169,9 @@ __device__ __forceinline__ void walk_cells(const NodeRec *__restrict__ rp, uint6
         const float4 q = r[b].cogm;
         const float dx = q.x - xi, dy = q.y - yi, dz = q.z - zi;
         const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
-        // negative size makes it always true, its self_pos excludes the body itself
-        const uint64_t far = __ballot(r[b].ssize2 < theta2 * r2);
+        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 / theta^2 < r^2; a leaf's
+        // negative radius makes it always true, its self_pos excludes the body itself
+        const uint64_t far = __ballot(r[b].mac2 < r2);
         const uint64_t other = __ballot(r[b].self_pos != i);
         const uint64_t take = gmask & far & other;
         const uint64_t open = gmask & ~far;  // never a leaf: its test is always true
@@ -1103,7 +1208,7 @@ __global__ __launch_bounds__(256) void walk_kernel(
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec,
     WalkRoots roots_arg,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
-    uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt, float theta,
+    uint32_t lo, uint32_t hi, uint32_t bpw_shift, float g, float e, float dt,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
     // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
@@ -1142,7 +1247,6 @@ __global__ __launch_bounds__(256) void walk_kernel(
         ay = part.y;
         az = part.z;
     }
-    const float theta2 = theta * theta;
     WalkStats st;
     const bool lane0 = lane == 0u;
 
@@ -1178,13 +1282,13 @@ __global__ __launch_bounds__(256) void walk_kernel(
             const NodeRec *rp = rec + first + c0;
             const uint32_t rem = gcnt - c0;
             if (rem >= 4u)
-                walk_cells<4, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+                walk_cells<4, COUNT>(rp, gmask, i, xi, yi, zi, e, ax, ay, az, stack, sp, lane0, st);
             else if (rem == 3u)
-                walk_cells<3, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+                walk_cells<3, COUNT>(rp, gmask, i, xi, yi, zi, e, ax, ay, az, stack, sp, lane0, st);
             else if (rem == 2u)
-                walk_cells<2, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+                walk_cells<2, COUNT>(rp, gmask, i, xi, yi, zi, e, ax, ay, az, stack, sp, lane0, st);
             else
-                walk_cells<1, COUNT>(rp, gmask, i, xi, yi, zi, theta2, e, ax, ay, az, stack, sp, lane0, st);
+                walk_cells<1, COUNT>(rp, gmask, i, xi, yi, zi, e, ax, ay, az, stack, sp, lane0, st);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1229,31 +1333,41 @@ __global__ __launch_bounds__(256) void walk_kernel(
 //     G = 8 (72 % at G = 4), and the scalar bookkeeping of the per-cell loop is gone;
 //   * a walk is a chain of ~25 batches instead of ~2,400 dependent cell visits, which is what
 //     bounds the small problems (benches/benchmark.rs sizes).
+// A stack entry: a cell and the set of the group's bodies that have to test it -- body b at bit G - 1 - b
+// ("low" format; the evaluation shifts it to the top of the word, where the carry of an add takes the
+// bodies out one by one).
 struct CellEnt {
-    uint32_t id, mask;  // bit 31 - b of mask: body b of the group has to test the cell
+    uint32_t id, mask;
 };
-// PACKED: the two in one word -- the mask uses the top 8 bits (G <= 8), a cell id below 2^24 the rest: half
+// PACKED: the two in one word -- the mask in the low byte (G <= 8), a cell id below 2^24 above it: half
 // the LDS traffic of the stack (walk -2 % at 2^20 bodies, -3 % at 4 M theta 0.75).  The host picks it
 // when every id the walk can meet (the tree's capacity, the LET import area) is below 2^24.
-constexpr uint32_t kPackedIdBits = 24, kPackedIdMask = (1u << kPackedIdBits) - 1u;
+constexpr uint32_t kPackedIdBits = 24;
 template <bool PACKED>
 struct CellStack;
 template <>
 struct CellStack<false> {
     using Ent = CellEnt;
     static __device__ __forceinline__ Ent make(uint32_t id, uint32_t mask) { return CellEnt{id, mask}; }
-    // the entry of child j of a cell whose first child is `first`
-    static __device__ __forceinline__ Ent child(uint32_t first, uint32_t mask, uint32_t j) { return CellEnt{first + j, mask}; }
+    // the entries of the children first, first + 1, ... of a cell: child(base(first, mask), j)
+    static __device__ __forceinline__ Ent base(uint32_t first, uint32_t mask) { return CellEnt{first, mask}; }
+    static __device__ __forceinline__ Ent child(const Ent &b, uint32_t j) { return CellEnt{b.id + j, b.mask}; }
     static __device__ __forceinline__ uint32_t id(const Ent &e) { return e.id; }
     static __device__ __forceinline__ uint32_t mask(const Ent &e) { return e.mask; }
+    // the mask with body b at bit 31 - b
+    template <int G>
+    static __device__ __forceinline__ uint32_t mask_top(const Ent &e) { return e.mask << (32 - G); }
 };
 template <>
 struct CellStack<true> {
     using Ent = uint32_t;
-    static __device__ __forceinline__ Ent make(uint32_t id, uint32_t mask) { return id | mask; }
-    static __device__ __forceinline__ Ent child(uint32_t first, uint32_t mask, uint32_t j) { return (first | mask) + j; }
-    static __device__ __forceinline__ uint32_t id(const Ent &e) { return e & kPackedIdMask; }
-    static __device__ __forceinline__ uint32_t mask(const Ent &e) { return e & ~kPackedIdMask; }
+    static __device__ __forceinline__ Ent make(uint32_t id, uint32_t mask) { return (id << 8) | mask; }
+    static __device__ __forceinline__ Ent base(uint32_t first, uint32_t mask) { return (first << 8) | mask; }
+    static __device__ __forceinline__ Ent child(const Ent &b, uint32_t j) { return b + (j << 8); }
+    static __device__ __forceinline__ uint32_t id(const Ent &e) { return e >> 8; }
+    static __device__ __forceinline__ uint32_t mask(const Ent &e) { return e & 0xffu; }
+    template <int G>
+    static __device__ __forceinline__ uint32_t mask_top(const Ent &e) { return e << (32 - G); }  // (the id falls off the top)
 };
 
 // The per-body lane sets come out of the per-lane masks one bit at a time through the carry of an
@@ -1318,30 +1432,31 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return __uint_as_float(x);
 }
 
-// One batch of the cells walk: the lane's cell (q = centre of gravity + mass, ssize2) against the G
-// bodies of the group.  vm: the bodies that have to test the cell (body b at bit 31 - b); returns
-// the bodies that open it (same format); a body whose bit is set and that accepts the cell takes it.
+// One batch of the cells walk: the lane's cell (q = centre of gravity + mass, mac2) against the G
+// bodies of the group.  vm: the bodies that have to test the cell, body b at bit 31 - b; returns
+// the bodies that open it, body b at bit G - 1 - b (the stack's format); a body whose bit is set and
+// that accepts the cell takes it.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Two bodies of the group per packed-fp32 instruction (v_pk_add/mul/fma_f32: two IEEE binary32
 // operations per lane and issue slot, each rounded as the scalar instruction rounds it, so every
 // bit is what the one-body-at-a-time form computes): bodies 2k and 2k+1 in the halves of bx[k].
 template <int G, bool COUNT>
-__device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssize2, uint32_t vm,
+__device__ __forceinline__ uint32_t cells_batch(const float4 q, const float mac2, uint32_t vm,
                                                 const v2f (&bx)[G / 2], const v2f (&by)[G / 2],
-                                                const v2f (&bz)[G / 2], const float theta2, const float e,
+                                                const v2f (&bz)[G / 2], const float e,
                                                 v2f (&ax)[G / 2], v2f (&ay)[G / 2], v2f (&az)[G / 2],
-                                                unsigned long long &n_accepts) {
+                                                unsigned long long &n_accepts, uint32_t &n_idle_pairs) {
     uint32_t om = 0u;  // body b ends up at bit G - 1 - b
 #pragma unroll
     for (int k = 0; k < G / 2; ++k) {
+        const uint64_t visit0 = shl1_carry_out(vm), visit1 = shl1_carry_out(vm);
+        if (COUNT && (visit0 | visit1) == 0ull) n_idle_pairs += 1u;  // (statistics: a pair no cell of the batch concerns)
         const v2f dx = v2f{q.x, q.x} - bx[k], dy = v2f{q.y, q.y} - by[k], dz = v2f{q.z, q.z} - bz[k];
         const v2f r2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 < theta^2 r^2; a leaf's
-        // negative size makes it always true.  Lane sets as 64-bit scalar masks.
-        const v2f t2 = v2f{theta2, theta2} * r2;
-        const uint64_t far0 = __ballot(ssize2 < t2.x), far1 = __ballot(ssize2 < t2.y);
-        const uint64_t visit0 = shl1_carry_out(vm), visit1 = shl1_carry_out(vm);
+        // acceptance size/dist < theta (tree.wgsl:63-64) as size^2 / theta^2 < r^2 (NodeRec::mac2); a leaf's
+        // negative radius makes it always true.  Lane sets as 64-bit scalar masks.
+        const uint64_t far0 = __ballot(mac2 < r2.x), far1 = __ballot(mac2 < r2.y);
         const uint64_t take0 = far0 & visit0, take1 = far1 & visit1;
         const uint64_t open0 = visit0 & ~far0, open1 = visit1 & ~far1;
         v2f dist;
@@ -1352,11 +1467,28 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
         rc.x = __builtin_amdgcn_rcpf(den.x);
         rc.y = __builtin_amdgcn_rcpf(den.y);
         v2f w = v2f{q.w, q.w} * rc;
-        w.x = __builtin_amdgcn_inverse_ballot_w64(take0) ? w.x : 0.0f;  // predicated, not branched
-        w.y = __builtin_amdgcn_inverse_ballot_w64(take1) ? w.y : 0.0f;
-        ax[k] = __builtin_elementwise_fma(w, dx, ax[k]);
-        ay[k] = __builtin_elementwise_fma(w, dy, ay[k]);
-        az[k] = __builtin_elementwise_fma(w, dz, az[k]);
+        {   // accumulate under the lanes that take the cell (exec = take), the other lanes' sums untouched:
+            // six plain fma instead of two selects and three packed fma
+            float a0 = ax[k].x, a1 = ay[k].x, a2 = az[k].x, b0 = ax[k].y, b1 = ay[k].y, b2 = az[k].y;
+            uint64_t saved;
+            asm("s_mov_b64 %[sv], exec\n\t"
+                "s_mov_b64 exec, %[t0]\n\t"
+                "v_fmac_f32 %[a0], %[w0], %[dx0]\n\t"
+                "v_fmac_f32 %[a1], %[w0], %[dy0]\n\t"
+                "v_fmac_f32 %[a2], %[w0], %[dz0]\n\t"
+                "s_mov_b64 exec, %[t1]\n\t"
+                "v_fmac_f32 %[b0], %[w1], %[dx1]\n\t"
+                "v_fmac_f32 %[b1], %[w1], %[dy1]\n\t"
+                "v_fmac_f32 %[b2], %[w1], %[dz1]\n\t"
+                "s_mov_b64 exec, %[sv]"
+                : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [b0] "+v"(b0), [b1] "+v"(b1), [b2] "+v"(b2),
+                  [sv] "=&s"(saved)
+                : [t0] "s"(take0), [t1] "s"(take1), [w0] "v"(w.x), [w1] "v"(w.y), [dx0] "v"(dx.x), [dy0] "v"(dy.x),
+                  [dz0] "v"(dz.x), [dx1] "v"(dx.y), [dy1] "v"(dy.y), [dz1] "v"(dz.y));
+            ax[k] = v2f{a0, b0};
+            ay[k] = v2f{a1, b1};
+            az[k] = v2f{a2, b2};
+        }
         om = shl1_carry_in(om, open0);
         om = shl1_carry_in(om, open1);
         if (COUNT)
@@ -1372,7 +1504,7 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float ssiz
         }
 #endif
     }
-    return om << (32 - G);  // the stack's format: body b at bit 31 - b
+    return om;
 }
 
 // roots.id[0 .. split) are walked together and reduced, then roots.id[split .. count): a LET host
@@ -1384,7 +1516,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots_arg, uint32_t split,
     float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
-    uint32_t lo, uint32_t hi, float g, float e, float dt, float theta,
+    uint32_t lo, uint32_t hi, float g, float e, float dt,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
     // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
@@ -1442,10 +1574,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     if (bound_slots && lane == 0u)  // the next step's root cube: max |coord| of the new positions
         publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
                                                      fmaxf(fabsf(blz), fabsf(bhz))));
-    const float theta2 = theta * theta;
-    const uint32_t root0 =  // a record every idle lane may read
-        (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->id[0] : roots_arg.id[0]));
-    const uint32_t group_mask = ~0u << (32u - nvalid);  // body b at bit 31 - b
+    const uint32_t group_mask = ((1u << nvalid) - 1u) << ((uint32_t)G - nvalid);  // body b at bit G - 1 - b
     Ent *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
     if (PART == 2 && owner) {
@@ -1455,7 +1584,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
         tz = part.z;
     }
     unsigned long long n_visits = 0, n_accepts = 0;
-    uint32_t n_cells = 0, n_leaves = 0, n_batches = 0, max_sp = 0;
+    uint32_t n_cells = 0, n_leaves = 0, n_batches = 0, max_sp = 0, n_idle_pairs = 0, n_evals = 0;
 #ifdef NB_DIAG_PHASES
     unsigned long long ph[4] = {0, 0, 0, 0};
 #endif
@@ -1480,60 +1609,68 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             // several cells is only taken while it leaves the reserve untouched -- the stack cannot
             // overflow on a consistent tree (the check below guards against a corrupt one).
             const uint32_t free_slots = kCellStack - sp;
-            const uint32_t lim = free_slots > kCellReserve ? (free_slots - kCellReserve) / 7u : 0u;
-            const uint32_t c = max(1u, min(min(64u, sp), lim));
             if (free_slots < 7u) {
                 overflowed = true;
                 break;
             }
+            uint32_t c = sp < 64u ? sp : 64u;
+            const uint32_t lim = free_slots >= kCellReserve + 7u ? (free_slots - kCellReserve) / 7u : 1u;
+            c = c < lim ? c : lim;
             sp -= c;
 #ifdef NB_DIAG_PHASES
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
-            // idle lanes (a batch of fewer than 64 cells) read a live stack slot and the root's
-            // record like everybody else and carry an empty visit mask: no divergent loads
-            const bool active = lane < c;
-            const Ent top = stack[sp + (active ? lane : 0u)];
-            const uint32_t cell = active ? Stack::id(top) : root0;
-            const uint32_t vm = active ? Stack::mask(top) : 0u;  // bodies that test this cell, body b at bit 31 - b
+            // the lanes past the batch (fewer than 64 cells) read its last entry and that cell's record like
+            // lane c - 1 -- no divergent load, no second address -- and carry an empty visit set
+            const uint64_t batch_lanes = ~0ull >> (64u - c);
+            const bool active = __builtin_amdgcn_inverse_ballot_w64(batch_lanes);
+            const Ent top = stack[sp + min(lane, c - 1u)];
+            // the bodies that test this cell, body b at bit 31 - b, where the carry of an add takes them out
+            const uint32_t vm = active ? Stack::template mask_top<G>(top) : 0u;
 #ifdef NB_DIAG_PHASES
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(cell), "v"(vm));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(top), "v"(vm));
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-            const NodeRec r = rec[cell];
+            // (a 32-bit byte offset from the uniform base: one shift and a load with a scalar base; the
+            // 64-bit form costs a 64-bit shift and a 64-bit add per batch)
+            const NodeRec r = *reinterpret_cast<const NodeRec *>(reinterpret_cast<const char *>(rec) +
+                                                                 (Stack::id(top) * (uint32_t)sizeof(NodeRec)));
 #ifdef NB_DIAG_PHASES
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(r.cogm.x), "v"(r.cogm.w), "v"(r.first), "v"(r.count), "v"(r.self_pos), "v"(r.ssize2));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(r.cogm.x), "v"(r.cogm.w), "v"(r.first), "v"(r.count), "v"(r.self_pos), "v"(r.mac2));
             const unsigned long long t2 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef NB_DIAG_EXTRA_LOAD   // sensitivity probe: one more divergent 32-byte record load per lane and batch
             {
-                const NodeRec r2 = rec[cell ^ 1u];
-                asm volatile("" ::"v"(r2.cogm.x), "v"(r2.cogm.w), "v"(r2.first), "v"(r2.ssize2));
+                const NodeRec r2 = rec[Stack::id(top) ^ 1u];
+                asm volatile("" ::"v"(r2.cogm.x), "v"(r2.cogm.w), "v"(r2.first), "v"(r2.mac2));
             }
 #endif
-            // a leaf is never taken by its own body; cells carry self_pos = ~0, no body of the group
-            const uint32_t sb = r.self_pos - i0;
             // The top of the tree: a batch of a few big cells (the root, its children; also the
             // roots of imported trees) that EVERY body of the group opens.  One test per lane against
             // the group's bounding box decides it without touching the bodies: with the largest
             // per-axis distance to the box, r2max >= the r^2 any body computes (fp32 subtract,
-            // multiply and fma are monotonic, same operation order), so "not (size^2 < theta^2
-            // r2max)" implies every body's own test says open -- the same decisions, 1/8 of the work.
+            // multiply and fma are monotonic, same operation order), so "not (mac2 < r2max)"
+            // implies every body's own test says open -- the same decisions, 1/8 of the work.
             bool all_open = false;
             if (c <= 8u) {
                 const float dxm = fmaxf(fabsf(r.cogm.x - blx), fabsf(r.cogm.x - bhx));
                 const float dym = fmaxf(fabsf(r.cogm.y - bly), fabsf(r.cogm.y - bhy));
                 const float dzm = fmaxf(fabsf(r.cogm.z - blz), fabsf(r.cogm.z - bhz));
                 const float r2max = __builtin_fmaf(dzm, dzm, __builtin_fmaf(dym, dym, dxm * dxm));
-                all_open = __ballot(active && (r.ssize2 < theta2 * r2max)) == 0ull;
+                all_open = (__ballot(r.mac2 < r2max) & batch_lanes) == 0ull;
             }
-            // (the leaf of one of the group's own bodies: that body's bit leaves the lane's set -- a
-            // leaf is never opened, so all the bit could do is take the leaf -- instead of a second
-            // evaluation path with "take" masks of its own)
-            uint32_t om = vm;
+            // the bodies that open the lane's cell, body b at bit G - 1 - b.  (Set before the branch and
+            // overwritten in it: written as if / else, the merge copies all 24 accumulators every batch.)
+            uint32_t om = active ? Stack::mask(top) : 0u;
             if (!all_open) {
-                const uint32_t em = sb < (uint32_t)G ? vm & ~(0x80000000u >> sb) : vm;
-                om = cells_batch<G, COUNT>(r.cogm, r.ssize2, em, bx, by, bz, theta2, e, ax, ay, az, n_accepts);
+                // a leaf is never taken by its own body (cells carry self_pos = ~0, no body of the group):
+                // that body's bit leaves the lane's set -- a leaf is never opened, so all the bit could do is
+                // take the leaf -- instead of a second evaluation path with "take" masks of its own.
+                // (bodies past the group's 8th clear a bit below the mask's)
+                const uint32_t sb = min(r.self_pos - i0, (uint32_t)G);
+                const uint32_t em = vm & ~(0x80000000u >> sb);
+                om = cells_batch<G, COUNT>(r.cogm, r.mac2, em, bx, by, bz, e, ax, ay, az, n_accepts, n_idle_pairs);
+                if (COUNT) n_evals += 1u;
             }
             if (COUNT) {
                 n_visits += (unsigned long long)__popc(vm);
@@ -1546,23 +1683,30 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
 #endif
             // push the children of the opened cells: lane l writes its cnt entries at
-            // sp + (children of the lanes below it), so siblings and cousins stay in lane order
-            const uint32_t cnt = om ? r.count : 0u;
-            const uint32_t incl = wave_scan_u32(cnt);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            Ent *dst = stack + sp + (incl - cnt);
-            // Every pushing lane stores all 8 slots, highest first, without looking at its count: a
-            // slot past a lane's count lands on a LOWER-numbered slot of a lane above it, which that
-            // lane stores later (or beyond the new top, inside the reserve) -- one predicate for
-            // the eight stores instead of eight.
-            if (cnt != 0u) {
+            // sp + (children of the lanes below it), so siblings and cousins stay in lane order.
+            // (An opened cell has children -- a leaf's test is always true -- so the lanes that push are
+            // the lanes with a body in om; a batch that opened nothing, which is most batches of leaves,
+            // skips the scan.)
+            const uint64_t pushers = __ballot(om != 0u);
+            if (pushers != 0ull) {
+                const uint32_t cnt = om != 0u ? r.count : 0u;
+                const uint32_t incl = wave_scan_u32(cnt);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                Ent *dst = stack + sp + (incl - cnt);
+                // Every pushing lane stores all 8 slots, highest first, without looking at its count: a
+                // slot past a lane's count lands on a LOWER-numbered slot of a lane above it, which that
+                // lane stores later (or beyond the new top, inside the reserve) -- one predicate for
+                // the eight stores instead of eight.
+                if (om != 0u) {
+                    const Ent cb = Stack::base(r.first, om);
 #pragma unroll
-                for (int j = 7; j >= 0; --j) {
-                    dst[j] = Stack::child(r.first, om, (uint32_t)j);
-                    __builtin_amdgcn_wave_barrier();  // keep the stores in this order
+                    for (int j = 7; j >= 0; --j) {
+                        dst[j] = Stack::child(cb, (uint32_t)j);
+                        __builtin_amdgcn_wave_barrier();  // keep the stores in this order
+                    }
                 }
+                sp += total;
             }
-            sp += total;
             if (COUNT) max_sp = max(max_sp, sp);
             __builtin_amdgcn_wave_barrier();
 #ifdef NB_DIAG_PHASES
@@ -1615,6 +1759,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             atomicMax(&counters[5], (unsigned long long)n_cells);  // the longest walk of any group
             atomicAdd(&counters[6], (unsigned long long)n_batches);
             atomicAdd(&counters[7], (unsigned long long)n_batches * (unsigned long long)(64 * G));
+            atomicAdd(&counters[8], (unsigned long long)n_idle_pairs);  // (batch, pair of bodies) with no visit at all
+            atomicAdd(&counters[9], (unsigned long long)n_evals);       // batches that ran the pair evaluation
         }
     }
 #ifdef NB_DIAG_PHASES
@@ -1716,7 +1862,7 @@ __global__ void let_global_bound_kernel(const uint32_t *__restrict__ meta_all, i
 __global__ __launch_bounds__(256) void let_export_level_kernel(
     const NodeRec *__restrict__ rec, const uint32_t *__restrict__ depth_base, int depth,
     const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap, const uint32_t *__restrict__ meta_all,
-    int rank, float theta2, bool prune, uint32_t *__restrict__ out_slot, NodeRec *__restrict__ send,
+    int rank, bool prune, uint32_t *__restrict__ out_slot, NodeRec *__restrict__ send,
     uint32_t *__restrict__ counts, uint32_t cap, uint32_t *__restrict__ status) {
     const int q = blockIdx.y;
     if (q == rank) return;
@@ -1750,7 +1896,7 @@ __global__ __launch_bounds__(256) void let_export_level_kernel(
                     const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
                     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     // some point of the box may open it: export the children too
-                    if ((!prune || !(r.ssize2 < theta2 * r2)) && r.first + r.count <= n_nodes) want = r.count;
+                    if ((!prune || !(r.mac2 < r2)) && r.first + r.count <= n_nodes) want = r.count;
                 }
             }
         }
@@ -1774,7 +1920,7 @@ __global__ __launch_bounds__(256) void let_export_level_kernel(
                 const uint32_t base = s_base + before + incl - want;
                 if (base + want <= cap) {
                     for (uint32_t c = 0; c < want; ++c) slots[r.first + c] = base + c;
-                    o = NodeRec{r.cogm, base, want, ~0u, r.ssize2};
+                    o = NodeRec{r.cogm, base, want, ~0u, r.mac2};
                 } else {
                     atomicAdd(&status[0], 1u);  // capacity exceeded: reported by check_status
                 }
@@ -1807,7 +1953,7 @@ constexpr uint32_t kLetExportThreads = 1024, kLetExportRanges = 3072;  // 2 list
 constexpr uint32_t kLetReserved = 73;  // the root, its 8 children, their 64 children: fixed slots
 
 __device__ __forceinline__ uint32_t let_export_want(const NodeRec &r, const float (&blo)[3], const float (&bhi)[3],
-                                                    float theta2, bool prune, uint32_t n_nodes) {
+                                                    bool prune, uint32_t n_nodes) {
     if (r.count == 0u) return 0u;
     // nearest point of the box to the centre of gravity, per axis, then r^2 in the walk's order
     const float dx = r.cogm.x - fminf(fmaxf(r.cogm.x, blo[0]), bhi[0]);
@@ -1815,12 +1961,12 @@ __device__ __forceinline__ uint32_t let_export_want(const NodeRec &r, const floa
     const float dz = r.cogm.z - fminf(fmaxf(r.cogm.z, blo[2]), bhi[2]);
     const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
     // some point of the box may open it: export the children too
-    return ((!prune || !(r.ssize2 < theta2 * r2)) && r.first + r.count <= n_nodes) ? r.count : 0u;
+    return ((!prune || !(r.mac2 < r2)) && r.first + r.count <= n_nodes) ? r.count : 0u;
 }
 
 __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
     const NodeRec *__restrict__ rec, const uint32_t *__restrict__ n_nodes_p, uint32_t n_cap,
-    const uint32_t *__restrict__ meta_all, int rank, float theta2, bool prune, NodeRec *send,
+    const uint32_t *__restrict__ meta_all, int rank, bool prune, NodeRec *send,
     uint32_t *__restrict__ counts, uint32_t cap, uint32_t *__restrict__ status) {
     const int q = blockIdx.y;
     const uint32_t sub = blockIdx.x, tid = threadIdx.x;
@@ -1835,13 +1981,13 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
     }
     NodeRec *out = send + (size_t)q * cap;
     const NodeRec root = rec[0];
-    const uint32_t want0 = cap >= kLetReserved ? let_export_want(root, blo, bhi, theta2, prune, n_nodes) : 0u;
+    const uint32_t want0 = cap >= kLetReserved ? let_export_want(root, blo, bhi, prune, n_nodes) : 0u;
     const NodeRec dummy{float4{0.f, 0.f, 0.f, 0.f}, 0u, 0u, ~0u, -1.0f};
     if (sub == 0u && tid < kLetReserved) {
         // slot 0: the root; 1 + c: child c of the root; 9 + 8 c + j: child j of that child (those that exist
         // and are exported are written by their own workgroups, the rest hold terminals nobody references)
         if (tid == 0u) {
-            out[0] = want0 ? NodeRec{root.cogm, 1u, want0, ~0u, root.ssize2} : NodeRec{root.cogm, 0u, 0u, ~0u, -1.0f};
+            out[0] = want0 ? NodeRec{root.cogm, 1u, want0, ~0u, root.mac2} : NodeRec{root.cogm, 0u, 0u, ~0u, -1.0f};
             if (!want0) counts[q] = 1u;  // (the counter starts at kLetReserved; nobody else touches it then)
         } else if (want0) {
             const uint32_t c = tid <= 8u ? tid - 1u : (tid - 9u) >> 3, j = (tid - 9u) & 7u;
@@ -1849,11 +1995,11 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
             uint32_t want1 = 0u;
             if (c < want0) {
                 rc = rec[root.first + c];
-                want1 = let_export_want(rc, blo, bhi, theta2, prune, n_nodes);
+                want1 = let_export_want(rc, blo, bhi, prune, n_nodes);
             }
             if (tid <= 8u) {
                 if (c < want0)
-                    out[tid] = want1 ? NodeRec{rc.cogm, 9u + 8u * c, want1, ~0u, rc.ssize2}
+                    out[tid] = want1 ? NodeRec{rc.cogm, 9u + 8u * c, want1, ~0u, rc.mac2}
                                      : NodeRec{rc.cogm, 0u, 0u, ~0u, -1.0f};
                 else
                     out[tid] = dummy;
@@ -1865,7 +2011,7 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
     const uint32_t c = sub >> 3, j = sub & 7u;
     if (c >= want0) return;
     const NodeRec rc = rec[root.first + c];
-    if (j >= let_export_want(rc, blo, bhi, theta2, prune, n_nodes)) return;
+    if (j >= let_export_want(rc, blo, bhi, prune, n_nodes)) return;
     const uint32_t seed_slot = 9u + 8u * c + j, seed_node = rc.first + j;
 
     __shared__ LetRange s_list[2][kLetExportRanges];
@@ -1891,7 +2037,7 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
                 uint32_t want = 0u;
                 if (valid) {
                     r = rec[out[slot].first];
-                    want = let_export_want(r, blo, bhi, theta2, prune, n_nodes);
+                    want = let_export_want(r, blo, bhi, prune, n_nodes);
                 }
                 uint32_t incl = want;
                 for (int o = 1; o < 64; o <<= 1) {
@@ -1925,7 +2071,7 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
                     if (want && s_base != ~0u) {
                         const uint32_t base = s_base + before + incl - want;
                         for (uint32_t c = 0; c < want; ++c) out[base + c].first = r.first + c;  // provisional
-                        o = NodeRec{r.cogm, base, want, ~0u, r.ssize2};
+                        o = NodeRec{r.cogm, base, want, ~0u, r.mac2};
                     }
                     out[slot] = o;
                 }
@@ -2046,7 +2192,7 @@ __global__ void let_rebase_kernel(NodeRec *__restrict__ imp, LetSegments segs, u
         } else {
             r.first = 0u;
             r.count = 0u;
-            r.ssize2 = -1.0f;
+            r.mac2 = -1.0f;
         }
     }
     imp[i] = r;
@@ -2088,7 +2234,7 @@ __global__ void let_rebase_fixed_kernel(NodeRec *__restrict__ imp, const uint32_
             } else {
                 rc.first = 0u;
                 rc.count = 0u;
-                rc.ssize2 = -1.0f;
+                rc.mac2 = -1.0f;
             }
         }
         seg[local] = rc;
@@ -2198,7 +2344,7 @@ class TreeSim final : public SimBase {
 #endif
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 128, stream));
         NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 16, stream));
-        NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 4, hipHostMallocDefault));
+        NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 8, hipHostMallocDefault));
         return write_particles(host, count);
     }
 
@@ -2211,6 +2357,10 @@ class TreeSim final : public SimBase {
         if (n == 0) return NB_OK;
         build_done = false;  // a build enqueued for the old state is void
         bound_from_walk = false;
+        // a graph captured after an eager step takes the root cube from the slots the previous walk
+        // filled and holds no bound_kernel: replayed on the new state it would key the bodies in the
+        // OLD state's cube.  Re-capture (the next capture starts from bound_kernel).
+        drop_graph();
         NB_HIP_TRY(hipMemcpyAsync(d_aos, host, sizeof(nb_particle) * (size_t)n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(tree_aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_aos, n,
                            posm[cur], vel[cur], acc[cur]);
@@ -2352,14 +2502,14 @@ class TreeSim final : public SimBase {
                 if (int rc = enqueue_build(true, true)) return rc;  // (a LET rank's velocities never travel)
                 if (one_launch) {
                     hipLaunchKernelGGL(let_export_kernel, dim3(64, let_world), dim3(kLetExportThreads), 0, stream, rec,
-                                       n_nodes, node_cap, let_meta, let_rank, theta * theta, let_prune, let_send,
+                                       n_nodes, node_cap, let_meta, let_rank, let_prune, let_send,
                                        my_counts, let_cap, status);
                 } else {
                     NB_HIP_TRY(hipMemsetAsync(let_out_slot, 0xff, sizeof(uint32_t) * (size_t)let_world * node_cap,
                                               stream));
                     for (int d = 0; d <= kMaxDepth; ++d)
                         hipLaunchKernelGGL(let_export_level_kernel, dim3(128, let_world), b256, 0, stream, rec,
-                                           depth_base, d, n_nodes, node_cap, let_meta, let_rank, theta * theta,
+                                           depth_base, d, n_nodes, node_cap, let_meta, let_rank,
                                            let_prune, let_out_slot, let_send, my_counts, let_cap, status);
                 }
                 hipLaunchKernelGGL(let_clamp_counts_kernel, dim3(1), dim3(64), 0, stream, my_counts, let_world,
@@ -2617,6 +2767,9 @@ class TreeSim final : public SimBase {
             bits = 6;
             while ((1ull << bits) < 64ull * n) ++bits;
             bits = std::min(63u, std::max(21u, bits));
+            // a step whose fix-up met a long run (a dense core in a cube stretched by escapers) makes the next
+            // steps sort more high digits (wait(): sort_boost), until the probe says they can go again
+            if (!rank_sort) bits = std::min(63u, bits + kSortBits * sort_boost);
         }
         const uint32_t W = (bits + kSortWideBits - 1u) / kSortWideBits < (bits + kSortBits - 1u) / kSortBits && sort_wide
                                ? kSortWideBits : kSortBits;
@@ -2668,9 +2821,15 @@ class TreeSim final : public SimBase {
 #undef NB_PASS
                 kb ^= 1;
             }
-            if (shift0)
+            if (shift0 || sort_boost) {  // (all 63 bits sorted: nothing to fix, but the probe still has to run)
+                const uint32_t par = build_seq & 1u;
                 hipLaunchKernelGGL(runs_fix_kernel, dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256, 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0);
+                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0,
+                                   sort_boost ? std::min(62u, shift0 + W) : 0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
+                run_stat_seq = build_seq;
+                run_stat_boost = sort_boost;
+                ++build_seq;
+            }
         }
         uint64_t *skeys = keys[kb];
         order = idx[kb];
@@ -2697,11 +2856,11 @@ class TreeSim final : public SimBase {
         if (n <= kFillEagerMax)
             hipLaunchKernelGGL((fill_kernel<false, true>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
         else
             hipLaunchKernelGGL((fill_kernel<false, false>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec);
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
         NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }
@@ -2734,7 +2893,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(COUNT, PART)                                                                              \
     hipLaunchKernelGGL((walk_kernel<COUNT, PART>), gwalk, b256, 0, stream, posm[d], vel[d], acc[d], rec,  \
                        roots, posm[s], vel[s], acc[s], lo, hi, shift, params.g, params.e, params.dt,      \
-                       theta, status, counters, bslots, roots_dev)
+                       status, counters, bslots, roots_dev)
             if (count_visits) {
                 if (part == 0) NB_WALK(true, 0); else if (part == 1) NB_WALK(true, 1); else NB_WALK(true, 2);
             } else {
@@ -2752,7 +2911,7 @@ class TreeSim final : public SimBase {
 #define NB_WALK(G, COUNT, PART, PACKED)                                                                           \
     hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART, PACKED>), gwalk, bwalk, 0, stream, posm[d], vel[d],      \
                        acc[d], rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt, \
-                       theta, status, counters, bslots, roots_dev)
+                       status, counters, bslots, roots_dev)
 #define NB_WALK_P(G, COUNT, PACKED)                                                           \
     do {                                                                                      \
         if (part == 0) NB_WALK(G, COUNT, 0, PACKED);                                          \
@@ -2794,13 +2953,31 @@ class TreeSim final : public SimBase {
     // the 4N node buffer, cut a LET export short, met inseparable bodies or tripped the walk's
     // stack guard must not look like a good step to a caller that never reads particles back
     // (nb_runner_step, the headless CLI, timing loops).  The words ride the same stream: one
-    // 16-byte copy into pinned memory ahead of the one synchronisation.
+    // 32-byte copy into pinned memory ahead of the one synchronisation -- the four status words and the
+    // fix-up's run statistics (runs_fix_kernel), which steer how many high digits the next builds sort.
     int wait() override {
         if (int rc = bind_device()) return rc;
         if (!h_status || !scalars) return SimBase::wait();
-        NB_HIP_TRY(hipMemcpyAsync(h_status, scalars + 4, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        NB_HIP_TRY(hipMemcpyAsync(h_status, scalars + 4, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, stream));
         NB_HIP_TRY(hipStreamSynchronize(stream));
+        adapt_sort(h_status + 4);
         return report_status(h_status);
+    }
+
+    // st: {longest run, parity 0; parity 1; probe flag, parity 0; parity 1} of the last two fix-ups.
+    // Speed only -- the sort's result does not depend on it -- so it does not matter which step's
+    // statistics a given wait() happens to see.
+    void adapt_sort(const uint32_t *st) {
+        if (run_stat_seq == ~0u || run_stat_seq == run_stat_seen) return;  // no fix-up since the last look
+        run_stat_seen = run_stat_seq;
+        const uint32_t par = run_stat_seq & 1u, longest = st[par], probe = st[2 + par];
+        const uint32_t before = sort_boost;
+        if (longest > kRunBoostAbove) {
+            sort_boost = std::min(kSortBoostMax, run_stat_boost + (longest > 256u * kRunBoostAbove ? 2u : 1u));
+        } else if (run_stat_boost != 0u && probe == 0u && sort_boost == run_stat_boost) {
+            sort_boost = run_stat_boost - 1u;  // with one digit less the runs would still be short
+        }
+        if (sort_boost != before) drop_graph();  // the captured launch sequence has the old number of passes
     }
 
     int check_status() {
@@ -2862,7 +3039,7 @@ class TreeSim final : public SimBase {
             hipLaunchKernelGGL((fill_kernel<true, false>), dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
                                n, node_cap, scalars + 1, node_first, node_depth, cpl, int_slot, leaf_id, int_id,
                                order, posm[cur ^ 1], mom_prefix, scalars + 16, scalars + 0, cogm, bodies, child,
-                               rec);
+                               rec, inv_theta2());
             hipLaunchKernelGGL(tree_to_aos_kernel, dim3((nodes + 255) / 256), dim3(256), 0, stream, cogm,
                                bodies, child, nodes, d_tree_aos);
             NB_HIP_TRY(hipMemcpyAsync(dst, d_tree_aos, sizeof(nb_octant) * m, hipMemcpyDeviceToHost, stream));
@@ -3126,6 +3303,8 @@ class TreeSim final : public SimBase {
     }
 
     float theta = NB_DEFAULT_THETA;
+    // what fill_kernel scales a cell's size^2 by (NodeRec::mac2); theta = 0 gives +inf: every cell is opened
+    float inv_theta2() const { return 1.0f / (theta * theta); }
     int cur = 0;  // posm/vel/acc[cur] hold the current state
     float4 *posm[2] = {nullptr, nullptr}, *vel[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr};
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -3168,6 +3347,9 @@ class TreeSim final : public SimBase {
     LetOwners let_owners{};
     hipGraphExec_t graph_exec = nullptr;
     uint32_t *h_status = nullptr;  // pinned mirror of the device status words (wait())
+    // extra high digits the radix passes cover (adapt_sort), and the fix-up launch its statistics belong to
+    static constexpr uint32_t kSortBoostMax = 6;
+    uint32_t sort_boost = 0, build_seq = 0, run_stat_seq = ~0u, run_stat_seen = ~0u, run_stat_boost = 0;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
