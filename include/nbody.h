@@ -363,6 +363,15 @@ int nb_runner_step(nb_runner *runner);
 /* n steps enqueued back to back, one wait at the end (benchmark use). */
 int nb_runner_step_n(nb_runner *runner, int n);
 
+/* Measurement (no reference counterpart).  With profiling on, every rank of a several-GPU runner records
+ * timing events on its stream at the borders between its own kernels and its waits for the peers' events;
+ * after nb_runner_step_n, nb_runner_rank_times gives, per rank, the milliseconds of that batch of steps spent in
+ * the rank's kernels (kernel_ms[r]) and waiting on the device for peers (wait_ms[r]).  n = the ranks the
+ * arrays hold.  A one-device runner reports the batch's time on its stream in kernel_ms[0].  Off by default:
+ * no event is recorded. */
+int nb_runner_set_profiling(nb_runner *runner, int on);
+int nb_runner_rank_times(nb_runner *runner, float *kernel_ms, float *wait_ms, int n);
+
 int nb_runner_read_particles(nb_runner *runner, nb_particle *dst, size_t n);
 int nb_runner_sim_params(const nb_runner *runner, nb_sim_params *out);
 int nb_runner_step_num(const nb_runner *runner, uint64_t *out);

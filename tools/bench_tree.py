@@ -26,6 +26,7 @@ ap.add_argument("--mode", type=int, default=None, help="walk kernel: 1 cells acr
 ap.add_argument("--group", type=int, default=None, help="bodies per wave of mode 1 (4/8/16)")
 ap.add_argument("--rounds", type=int, default=None, help="256-body rounds per workgroup of the cells kernels")
 ap.add_argument("--sort", type=int, default=None, help="sort: 1 one-sweep (default), 0 three kernels per digit")
+ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="any tuning key of nb_sim_set_tuning")
 ap.add_argument("--cpu-baseline", action="store_true",
                 help="also time the CPU oracle: the reference's serial BFS build + DFS reorder "
                      "(src/sims/tree.rs:417-602, single thread as in the reference) and the "
@@ -48,6 +49,9 @@ if args.rounds is not None:
     sim.set_tuning("tree_cell_rounds", args.rounds)
 if args.bpw is not None:
     sim.set_tuning("tree_walk_bpw", args.bpw)
+for kv in args.tune:
+    key, value = kv.split("=")
+    sim.set_tuning(key, int(value))
 sim.set_tuning("tree_count_visits", 1)
 sim.encode(); sim.wait()
 c0 = sim.debug_buffer("counters", np.uint64).copy()

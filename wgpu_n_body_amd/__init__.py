@@ -403,6 +403,16 @@ class OfflineHeadless:
     def step_n(self, n: int) -> None:
         check(_lib.lib().nb_runner_step_n(self._h, int(n)))
 
+    def set_profiling(self, on: bool = True) -> None:
+        """Measurement: timing events around every rank's kernels and its waits for the peers."""
+        check(_lib.lib().nb_runner_set_profiling(self._h, 1 if on else 0))
+
+    def rank_times(self, world: int):
+        """(kernel_ms[world], wait_ms[world]) of the last step_n() with profiling on."""
+        k, w = (C.c_float * world)(), (C.c_float * world)()
+        check(_lib.lib().nb_runner_rank_times(self._h, k, w, world))
+        return [float(x) for x in k], [float(x) for x in w]
+
     def read_particles(self) -> np.ndarray:
         n = self.sim_params().particle_num
         out = np.zeros(n, dtype=PARTICLE_DTYPE)

@@ -57,6 +57,7 @@ ABI_SYMBOLS = [
     "nb_sim_exchange_region_i", "nb_sim_step_num", "nb_sim_encode_n_timed",
     "nb_sim_set_tuning", "nb_sim_debug_buffer", "nb_naive_variant_count", "nb_naive_variant_name", "nb_sim_destroy",
     "nb_runner_create", "nb_runner_create_multi", "nb_runner_create_multi_let", "nb_runner_step_num", "nb_runner_step", "nb_runner_step_n", "nb_runner_read_particles",
+    "nb_runner_set_profiling", "nb_runner_rank_times",
     "nb_runner_sim_params", "nb_runner_sim", "nb_runner_destroy",
 ]
 
@@ -125,6 +126,8 @@ def lib() -> C.CDLL:
     L.nb_runner_step.argtypes = [vp]
     L.nb_runner_step_n.argtypes = [vp, C.c_int]
     L.nb_runner_read_particles.argtypes = [vp, vp, sz]
+    L.nb_runner_set_profiling.argtypes = [vp, C.c_int]
+    L.nb_runner_rank_times.argtypes = [vp, P(C.c_float), P(C.c_float), C.c_int]
     L.nb_runner_sim_params.argtypes = [vp, P(nb_sim_params)]
     L.nb_runner_sim.argtypes = [vp]
     L.nb_runner_sim.restype = vp

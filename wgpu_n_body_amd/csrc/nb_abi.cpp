@@ -588,6 +588,8 @@ int nb_sim_destroy(nb_sim *sim) {
 struct nb_runner {
     nb_sim *sim = nullptr;                  // one device
     std::unique_ptr<DeviceGroup> group;      // several devices of this process (nb_runner_create_multi)
+    bool profiling = false;                  // nb_runner_set_profiling, one device: events around step_n
+    float kernel_ms = 0.f;
 };
 
 int nb_runner_create(nb_runner **out, const nb_sim_params *sim_params,
@@ -676,11 +678,45 @@ int nb_runner_step_n(nb_runner *runner, int n) {
         return NB_ERR_INVALID;
     }
     if (runner->group) NB_GUARD({ return runner->group->step_n(n); })
-    for (int k = 0; k < n; ++k) {
-        if (int rc = nb_sim_encode(runner->sim)) return rc;
-        if (int rc = nb_sim_cleanup(runner->sim)) return rc;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const bool prof = runner->profiling && runner->sim->impl && runner->sim->impl->bind_device() == NB_OK &&
+                      hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+    if (prof) (void)hipEventRecord(ev[0], runner->sim->impl->stream);
+    int rc = NB_OK;
+    for (int k = 0; k < n && rc == NB_OK; ++k) {
+        rc = nb_sim_encode(runner->sim);
+        if (rc == NB_OK) rc = nb_sim_cleanup(runner->sim);
     }
-    return nb_sim_wait(runner->sim);
+    if (prof) (void)hipEventRecord(ev[1], runner->sim->impl->stream);
+    const int rw = nb_sim_wait(runner->sim);
+    if (prof && hipEventElapsedTime(&runner->kernel_ms, ev[0], ev[1]) != hipSuccess) runner->kernel_ms = 0.f;
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return rc != NB_OK ? rc : rw;
+}
+
+int nb_runner_set_profiling(nb_runner *runner, int on) {
+    if (!runner || (!runner->sim && !runner->group)) {
+        set_error("null runner");
+        return NB_ERR_INVALID;
+    }
+    runner->profiling = on != 0;
+    if (runner->group) return runner->group->set_profiling(on != 0);
+    return NB_OK;
+}
+
+int nb_runner_rank_times(nb_runner *runner, float *kernel_ms, float *wait_ms, int n) {
+    if (!runner || (!runner->sim && !runner->group) || n < 1) {
+        set_error("null runner");
+        return NB_ERR_INVALID;
+    }
+    for (int r = 0; r < n; ++r) {
+        if (kernel_ms) kernel_ms[r] = 0.f;
+        if (wait_ms) wait_ms[r] = 0.f;
+    }
+    if (runner->group) return runner->group->rank_times(kernel_ms, wait_ms, n);
+    if (kernel_ms) kernel_ms[0] = runner->kernel_ms;
+    return NB_OK;
 }
 
 int nb_runner_read_particles(nb_runner *runner, nb_particle *dst, size_t n) {

@@ -44,6 +44,15 @@ struct PeerDst {
     uint32_t n;
 };
 
+// a word in every peer's table (the create-time check that peer stores arrive: nb_naive.hip, nb_group.cpp)
+struct PeerWords {
+    uint32_t *p[kMaxPeers];
+    uint32_t n;
+};
+hipError_t launch_peer_check_store(const PeerWords &dst, uint32_t slot, uint32_t value, hipStream_t stream);
+hipError_t launch_peer_check_read(const uint32_t *words, uint32_t world, uint32_t me, uint32_t tag, uint32_t *bad,
+                                  hipStream_t stream);
+
 // ---- launchers implemented in nb_naive.hip ----------------------------------
 struct NaiveLaunch {
     const float4 *posm_src;  // [n_pad] x,y,z,m  (previous step, all bodies)

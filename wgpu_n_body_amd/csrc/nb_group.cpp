@@ -72,8 +72,43 @@ class HostBarrier {
 };
 }  // namespace
 
+// Measurement (nb_runner_set_profiling): timing events on the rank's stream at the borders between "the
+// rank's own kernels" and "waiting for a peer's event"; after the batch has drained, the time between two
+// consecutive marks goes to the kind of the earlier one.  Off by default: nothing is recorded.
+struct RankProf {
+    enum Kind : uint8_t { kKernel = 0, kWait = 1, kEnd = 2 };
+    std::vector<hipEvent_t> ev;
+    std::vector<uint8_t> kind;
+    size_t used = 0;
+    float ms[2] = {0.f, 0.f};
+    void mark(bool on, Kind k, hipStream_t stream) {
+        if (!on) return;
+        if (used == ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ev.push_back(e);
+            kind.push_back(0);
+        }
+        if (hipEventRecord(ev[used], stream) != hipSuccess) return;
+        kind[used++] = (uint8_t)k;
+    }
+    void collect() {  // (the stream has drained)
+        ms[0] = ms[1] = 0.f;
+        for (size_t i = 0; i + 1 < used; ++i) {
+            float t = 0.f;
+            if (kind[i] != kEnd && hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms[kind[i]] += t;
+        }
+        used = 0;
+    }
+    void destroy() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+};
+
 struct DeviceGroup::Rank {
     std::unique_ptr<SimBase> sim;
+    RankProf prof;
     NaiveSim *naive = nullptr;
     int device = 0;
     hipEvent_t done[2] = {nullptr, nullptr};
@@ -92,7 +127,9 @@ struct DeviceGroup::Shared {
     int cmd_steps = 0;
     int finished = 0;
     bool quit = false;
-    bool failed = false;   // some rank hit an error: the others stop working but keep meeting
+    std::atomic<bool> failed{false};  // some rank hit an error: the others stop working but keep meeting
+    std::atomic<bool> profiling{false};
+    int prof_steps = 0;
     std::unique_ptr<HostBarrier> bar;
     std::vector<uint32_t> mig;  // LET migration: world x world leaver counts, row r written by rank r's thread
 };
@@ -116,6 +153,7 @@ DeviceGroup::~DeviceGroup() {
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : r->meta)
             if (e) (void)hipEventDestroy(e);
+        r->prof.destroy();
         r->sim.reset();
     }
 }
@@ -314,6 +352,8 @@ int DeviceGroup::create(std::unique_ptr<DeviceGroup> &out, const nb_sim_params &
             (void)hipGetLastError();
         }
     }
+    if (world > 1)
+        if (int rc = g->check_peer_stores()) return rc;
     for (int r = 0; r < world && !g->tree_; ++r) {
         float4 *b0[kMaxPeers], *b1[kMaxPeers];
         int k = 0;
@@ -333,12 +373,77 @@ int DeviceGroup::create(std::unique_ptr<DeviceGroup> &out, const nb_sim_params &
     return NB_OK;
 }
 
+// What every step of every scheme relies on, rehearsed once with one word per ordered pair of ranks: rank r's
+// kernel stores (tag | r) into word r of every peer's table through peer access and records an event; every
+// peer's stream waits for the events and a kernel of its own reads its table with plain loads.  A platform where
+// that does not hold -- a peer mapping that is not there after all, a cache the event wait does not make
+// coherent -- is reported here instead of producing wrong forces later.  (Ranks sharing a device run it too:
+// the same code, minus the links.)
+int DeviceGroup::check_peer_stores() {
+    const int world = (int)ranks_.size();
+    const uint32_t tag = 0xC0DE0000u;
+    std::vector<uint32_t *> table((size_t)world, nullptr), bad((size_t)world, nullptr);
+    std::vector<hipEvent_t> stored((size_t)world, nullptr);
+    int rc = NB_OK;
+    auto hip = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == NB_OK) {
+            set_error("peer-store check: %s failed: %s", what, hipGetErrorString(e));
+            rc = NB_ERR_HIP;
+        }
+        return e == hipSuccess;
+    };
+    for (int r = 0; r < world && rc == NB_OK; ++r) {
+        hip(hipSetDevice(ranks_[r]->device), "hipSetDevice");
+        hip(hipMalloc((void **)&table[r], sizeof(uint32_t) * ((size_t)world + 1)), "hipMalloc");
+        bad[r] = table[r] ? table[r] + world : nullptr;
+        if (table[r]) hip(hipMemsetAsync(table[r], 0, sizeof(uint32_t) * ((size_t)world + 1), ranks_[r]->sim->stream), "hipMemsetAsync");
+        hip(hipEventCreateWithFlags(&stored[r], hipEventDisableTiming), "hipEventCreate");
+        hip(hipStreamSynchronize(ranks_[r]->sim->stream), "hipStreamSynchronize");
+    }
+    for (int r = 0; r < world && rc == NB_OK; ++r) {  // the stores
+        hip(hipSetDevice(ranks_[r]->device), "hipSetDevice");
+        PeerWords dst{};
+        for (int q = 0; q < world; ++q)
+            if (q != r) dst.p[dst.n++] = table[q];
+        hip(launch_peer_check_store(dst, (uint32_t)r, tag | (uint32_t)r, ranks_[r]->sim->stream), "store kernel");
+        hip(hipEventRecord(stored[r], ranks_[r]->sim->stream), "hipEventRecord");
+    }
+    for (int q = 0; q < world && rc == NB_OK; ++q) {  // the reads, behind the events
+        hip(hipSetDevice(ranks_[q]->device), "hipSetDevice");
+        for (int r = 0; r < world; ++r)
+            if (r != q) hip(hipStreamWaitEvent(ranks_[q]->sim->stream, stored[r], 0), "hipStreamWaitEvent");
+        hip(launch_peer_check_read(table[q], (uint32_t)world, (uint32_t)q, tag, bad[q], ranks_[q]->sim->stream), "read kernel");
+    }
+    for (int q = 0; q < world && rc == NB_OK; ++q) {
+        hip(hipSetDevice(ranks_[q]->device), "hipSetDevice");
+        uint32_t nbad = 0;
+        hip(hipMemcpyAsync(&nbad, bad[q], sizeof nbad, hipMemcpyDeviceToHost, ranks_[q]->sim->stream), "hipMemcpyAsync");
+        hip(hipStreamSynchronize(ranks_[q]->sim->stream), "hipStreamSynchronize");
+        if (rc == NB_OK && nbad) {
+            set_error("peer-store check: %u of the %d words that peers stored into device %d's memory (rank %d) did not "
+                      "arrive behind their events: this platform does not give the one-process runner the "
+                      "visibility it needs (use one process per GPU: nb_placement + RCCL)",
+                      nbad, world - 1, ranks_[q]->device, q);
+            rc = NB_ERR_UNSUPPORTED;
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        (void)hipSetDevice(ranks_[r]->device);
+        if (stored[r]) (void)hipEventDestroy(stored[r]);
+        if (table[r]) (void)hipFree(table[r]);
+    }
+    return rc;
+}
+
 // One LET step of rank r (see create_let).  Every rank thread passes the same barriers whatever fails.
 template <typename Fail, typename Failed>
 void DeviceGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
     Rank &me = *ranks_[r];
     SimBase &sim = *me.sim;
     const int world = (int)ranks_.size();
+    const bool prof = sh_->profiling.load(std::memory_order_relaxed);
+    auto mark_k = [&] { me.prof.mark(prof, RankProf::kKernel, sim.stream); };
+    auto mark_w = [&] { me.prof.mark(prof, RankProf::kWait, sim.stream); };
     auto hip_ok = [&](hipError_t e, const char *what) {
         if (e == hipSuccess) return true;
         set_error("%s failed: %s", what, hipGetErrorString(e));
@@ -355,12 +460,14 @@ void DeviceGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
         return true;
     };
     auto wait_peers = [&](int which, uint64_t idx) {  // 0 meta, 1 pushed, 2 done
+        mark_w();
         for (int q = 0; q < world; ++q) {
             if (q == r) continue;
             Rank &p = *ranks_[q];
             hipEvent_t ev = which == 0 ? p.meta[idx & 1] : which == 1 ? p.pushed[idx & 1] : p.done[idx & 1];
             if (!hip_ok(hipStreamWaitEvent(sim.stream, ev, 0), "hipStreamWaitEvent")) return;
         }
+        mark_k();
     };
     auto peers_of = [&](int k, void **bases) {  // bases of region k on every peer, in rank order
         int np = 0;
@@ -373,6 +480,7 @@ void DeviceGroup::let_step(int r, uint64_t t, Fail &fail, Failed &failed) {
     };
 
     const bool migrate = migrate_every_ > 0 && t > 0 && t % (uint64_t)migrate_every_ == 0;
+    mark_k();
     if (migrate) {
         // the bodies that left this rank's key range go to their new owners: leaver counts read on the
         // host (they size the next launches), leavers pulled from the peers' send areas
@@ -481,13 +589,14 @@ void DeviceGroup::worker(int r) {
                 me.rc = rc;
                 me.err = nb_last_error();
             }
-            std::lock_guard<std::mutex> lk(sh_->mu);
-            sh_->failed = true;
+            sh_->failed.store(true, std::memory_order_release);
         };
-        auto failed = [&] {
-            std::lock_guard<std::mutex> lk(sh_->mu);
-            return sh_->failed;
-        };
+        // (asked several times per step and rank: a relaxed load, not the group's mutex -- a rank that sees the
+        // flag a step late only enqueues one more step of work that nobody reads)
+        auto failed = [&] { return sh_->failed.load(std::memory_order_relaxed); };
+        const bool prof = sh_->profiling.load(std::memory_order_relaxed);
+        auto mark_k = [&] { me.prof.mark(prof, RankProf::kKernel, me.sim->stream); };
+        auto mark_w = [&] { me.prof.mark(prof, RankProf::kWait, me.sim->stream); };
         // this rank's stream waits for every peer's event of step idx ("slices pushed" or "step finished")
         auto wait_all = [&](bool pushed_ev, uint64_t idx) -> hipError_t {
             hipError_t e = hipSuccess;
@@ -503,7 +612,9 @@ void DeviceGroup::worker(int r) {
             const uint64_t t = step_ + (uint64_t)s;
             sh_->bar->wait();  // every rank has recorded its "slices of step t-1 pushed"
             if (!failed()) {
+                mark_w();
                 hipError_t e = t > 0 ? wait_all(true, t - 1) : hipSuccess;
+                mark_k();
                 if (e != hipSuccess) {
                     set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
                     fail(NB_ERR_HIP);
@@ -516,7 +627,9 @@ void DeviceGroup::worker(int r) {
             }
             sh_->bar->wait();  // every rank has recorded its "step t finished"
             if (!failed()) {
+                mark_w();
                 hipError_t e = wait_all(false, t);
+                mark_k();
                 // positions/masses, velocities, accelerations: one launch stores the slices into every peer
                 void *bases[3 * kMaxPeers];
                 int np = 0;
@@ -539,11 +652,15 @@ void DeviceGroup::worker(int r) {
         }
         for (int s = 0; s < steps && !tree_; ++s) {
             const uint64_t t = step_ + (uint64_t)s;  // absolute step index (same on every rank)
-            if (!failed())
+            if (!failed()) {
+                mark_k();
                 if (int rc = me.sim->encode_phase(0)) fail(rc);  // own j tiles: nothing to wait for
+            }
             sh_->bar->wait();  // every rank has recorded its "step t-1 finished"
             if (!failed()) {
+                mark_w();
                 hipError_t e = t > 0 ? wait_all(false, t - 1) : hipSuccess;
+                mark_k();
                 if (e != hipSuccess) {
                     set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e));
                     fail(NB_ERR_HIP);
@@ -555,7 +672,9 @@ void DeviceGroup::worker(int r) {
                 }
             }
         }
+        me.prof.mark(prof, RankProf::kEnd, me.sim->stream);
         if (int rc = me.sim->wait()) fail(rc);
+        if (prof) me.prof.collect();
         sh_->bar->wait();  // every stream has drained: all slices have landed everywhere
         {
             std::lock_guard<std::mutex> lk(sh_->mu);
@@ -569,7 +688,7 @@ int DeviceGroup::step_n(int steps) {
     if (steps <= 0) return NB_OK;
     {
         std::lock_guard<std::mutex> lk(sh_->mu);
-        if (sh_->failed) {
+        if (sh_->failed.load()) {
             set_error("the runner is in a failed state: %s", first_error().c_str());
             return NB_ERR_INVALID;
         }
@@ -588,6 +707,21 @@ int DeviceGroup::step_n(int steps) {
             set_error("rank on device %d: %s", r->device, r->err.c_str());
             return r->rc;
         }
+    return NB_OK;
+}
+
+int DeviceGroup::set_profiling(bool on) {
+    sh_->profiling.store(on);
+    return NB_OK;
+}
+
+// per rank: milliseconds of the LAST batch of steps spent in the rank's own kernels and waiting (on the device)
+// for the peers' events
+int DeviceGroup::rank_times(float *kernel_ms, float *wait_ms, int n) const {
+    for (int r = 0; r < n && r < (int)ranks_.size(); ++r) {
+        if (kernel_ms) kernel_ms[r] = ranks_[(size_t)r]->prof.ms[RankProf::kKernel];
+        if (wait_ms) wait_ms[r] = ranks_[(size_t)r]->prof.ms[RankProf::kWait];
+    }
     return NB_OK;
 }
 

@@ -24,6 +24,9 @@ class DeviceGroup {
     const nb_sim_params &params() const { return params_; }
     int world() const { return (int)ranks_.size(); }
     uint64_t step_num() const { return step_; }
+    // measurement: timing events around every rank's kernels and waits (nb_runner_set_profiling / _rank_times)
+    int set_profiling(bool on);
+    int rank_times(float *kernel_ms, float *wait_ms, int n) const;
 
    private:
     DeviceGroup();
@@ -35,6 +38,7 @@ class DeviceGroup {
     template <typename Fail, typename Failed>
     void let_step(int r, uint64_t t, Fail &fail, Failed &failed);
     std::string first_error() const;
+    int check_peer_stores();  // create time: peer stores arrive behind their events (or NB_ERR_UNSUPPORTED)
     std::vector<std::unique_ptr<Rank>> ranks_;
     std::unique_ptr<Shared> sh_;
     nb_sim_params params_{};

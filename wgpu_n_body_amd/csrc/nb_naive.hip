@@ -475,4 +475,30 @@ hipError_t launch_soa_to_aos(const float4 *posm, const float4 *vel, const float4
     return hipGetLastError();
 }
 
+// ---- one-process multi-GPU runner: does a peer store arrive the way the step relies on? -------------------
+// The exchange of nb_group.cpp is "a kernel on device A stores into device B's memory through peer access; A
+// records an event; B's stream waits for it; B's next kernel reads the bytes with plain loads".  These two
+// kernels rehearse exactly that once, at create time, with one word per ordered pair of ranks, so that a
+// platform where it does not hold (no peer mapping after all, a cache the wait does not flush) is reported
+// instead of computing garbage.
+__global__ void peer_check_store_kernel(PeerWords dst, uint32_t slot, uint32_t value) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < dst.n) dst.p[q][slot] = value;
+}
+__global__ void peer_check_read_kernel(const uint32_t *__restrict__ words, uint32_t world, uint32_t me, uint32_t tag,
+                                       uint32_t *__restrict__ bad) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < world && r != me && words[r] != (tag | r)) atomicAdd(bad, 1u);
+}
+
+hipError_t launch_peer_check_store(const PeerWords &dst, uint32_t slot, uint32_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(peer_check_store_kernel, dim3(1), dim3(64), 0, stream, dst, slot, value);
+    return hipGetLastError();
+}
+hipError_t launch_peer_check_read(const uint32_t *words, uint32_t world, uint32_t me, uint32_t tag, uint32_t *bad,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(peer_check_read_kernel, dim3(1), dim3(64), 0, stream, words, world, me, tag, bad);
+    return hipGetLastError();
+}
+
 }  // namespace nb

@@ -110,7 +110,9 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
                                                               uint32_t *__restrict__ idx,
                                                               uint32_t *__restrict__ hist, uint32_t nblocks,
                                                               uint32_t items, uint32_t hist_shift,
-                                                              uint32_t hist_bins) {
+                                                              uint32_t hist_bins, uint32_t *__restrict__ key_hi) {
+    // key_hi (the radix passes sort 32-bit high words paired with indices, section 3e): the high word of
+    // every key beside the key, and no identity index array -- the first pass makes it up.
     // (blockDim.x * items bodies = a sort tile: a workgroup leaves the tile's histogram of the digit the
     // FIRST radix pass sorts by -- hist_bins values at bit hist_shift; the counting sort of small
     // problems needs no histogram and takes items = 1: more, shorter workgroups)
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
             w = w / 2.0f;
         }
         keys[i] = key;
-        idx[i] = i;
+        if (key_hi) key_hi[i] = (uint32_t)(key >> 32);
+        else idx[i] = i;
         if (hist) atomicAdd(&s_hist[(uint32_t)(key >> hist_shift) & (hist_bins - 1u)], 1u);
     }
     __syncthreads();
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
 // per element where it lands, was measured and dropped: 47 instead of 12 us per scatter at 2^20
 // bodies, 10.8 instead of 5 + 5 at 8,192 -- profiles/r02_sort_experiments.txt.)
 // (ITEMS elements per thread of a 2 x kSortThreads workgroup: the tile of the scatter, whatever its order inside)
-template <uint32_t ITEMS>
+template <uint32_t ITEMS, typename KeyT = uint64_t>
 __global__ __launch_bounds__(2 * kSortThreads) void radix_hist_kernel(
-    const uint64_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins, uint32_t *__restrict__ hist,
+    const KeyT *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t bins, uint32_t *__restrict__ hist,
     uint32_t nblocks) {
     constexpr uint32_t THREADS = 2u * kSortThreads;
     __shared__ uint32_t s_hist[kSortMaxBins];
@@ -235,10 +238,12 @@ __device__ __forceinline__ uint32_t sort_scan_block(uint32_t v, uint32_t *s_w) {
 // bin_scan launch of the pass.  Thread t looks after the digits [t PER, (t + 1) PER).
 // THREADS x ITEMS elements = a sort tile (2,048-element tiles run as 512 threads x 4: twice the waves per SIMD
 // of 256 x 8 for a kernel that is a chain of LDS round trips and barriers).
-template <int W, uint32_t THREADS, uint32_t ITEMS, bool SCAN_INLINE>
+// KeyT = uint32_t: the high words of the keys (section 3e) -- 8-byte instead of 12-byte elements; vals_in = null:
+// the values are the positions themselves (the first pass: no identity array is ever written or read).
+template <int W, uint32_t THREADS, uint32_t ITEMS, bool SCAN_INLINE, typename KeyT = uint64_t>
 __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
-    const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
+    const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t shift,
     const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals, uint32_t nblocks) {
     constexpr uint32_t NB = 1u << W, PER = (NB + THREADS - 1u) / THREADS, TILE = THREADS * ITEMS, NWV = THREADS / 64u;
     __shared__ uint32_t s_cnt[NWV][NB];  // per-wave running digit counts -> exclusive wave offsets
@@ -280,14 +285,14 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 
     const uint32_t base = blockIdx.x * TILE + wave * (64 * ITEMS);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint64_t key[ITEMS];
+    KeyT key[ITEMS];
     uint32_t val[ITEMS], local[ITEMS];
 #pragma unroll
     for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t i = base + c * 64 + lane;
         const bool valid = i < n;
-        key[c] = valid ? keys_in[i] : ~0ull;
-        val[c] = valid ? vals_in[i] : 0u;
+        key[c] = valid ? keys_in[i] : (KeyT)~(KeyT)0;
+        val[c] = !valid ? 0u : vals_in ? vals_in[i] : i;
         const uint32_t d = (uint32_t)(key[c] >> shift) & (NB - 1u);
         // lanes holding the same digit (ballot match over the W digit bits)
         uint64_t peers = __ballot(valid);
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     // Stage the tile in LDS in digit order, then write it out with consecutive threads on
     // consecutive elements: each digit's run lands in global memory as one contiguous, coalesced
     // stream instead of 64 scattered 8-byte stores per wave instruction.
-    __shared__ uint64_t s_key[TILE];
+    __shared__ KeyT s_key[TILE];
     __shared__ uint32_t s_val[TILE];
 #pragma unroll
     for (uint32_t c = 0; c < ITEMS; ++c) {
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     for (uint32_t c = 0; c < ITEMS; ++c) {
         const uint32_t j = c * THREADS + threadIdx.x;
         if (j < tile_n) {
-            const uint64_t k = s_key[j];
+            const KeyT k = s_key[j];
             const uint32_t d = (uint32_t)(k >> shift) & (NB - 1u);
             const uint32_t dst = s_base[d] + (j - s_tile[d]);
             keys_out[dst] = k;
@@ -531,12 +536,25 @@ __device__ void run_radix_sort(uint64_t *keys, uint32_t *vals, uint64_t *alt_key
 // stat[0]: the longest run met (atomicMax; the launch of the step before zeroed it: stat_clear = the word
 // of the other parity).  stat[2], with probe_bits != 0: set if some run of keys that tie on all but their low
 // probe_bits bits is longer than kRunProbeSpan -- what the fix-up would meet with one high digit less.
-__global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+//
+// HI (section 3e: the passes sorted 32-bit high words paired with indices; low_bits >= 32): the runs are
+// found on the sorted high words `khi`, a body's full key is keys[vals[position]] -- the unsorted keys,
+// gathered only for the few bodies inside runs -- and only `vals` is permuted: the high word of a body is the
+// same anywhere in its run's bits that matter.  A long run's keys are gathered into `run_keys` first
+// (scratch, indexed like the run) and sorted there beside the indices.  !HI: `keys` is the sorted key array
+// itself, permuted in place together with `vals`; run_keys = keys.
+template <bool HI>
+__global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restrict__ khi, const uint64_t *keys,
+                                                       uint64_t *run_keys, uint32_t *__restrict__ vals,
                                                        uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
                                                        uint32_t n, uint32_t low_bits, uint32_t probe_bits,
                                                        uint32_t *__restrict__ stat, uint32_t *__restrict__ stat_clear) {
     __shared__ uint32_t s_short[256 * kRunItems], s_long[256 * kRunItems / kRunWave + 1], s_n[3];
     __shared__ uint32_t s_hist[256], s_wcnt[4][256], s_w[4], s_flag;
+    // the bits a run ties on, and the coarser ones the probe looks at
+    auto high = [&](uint32_t k) -> uint64_t { return HI ? (uint64_t)(khi[k] >> (low_bits - 32u)) : keys[k] >> low_bits; };
+    auto coarse = [&](uint32_t k) -> uint64_t { return HI ? (uint64_t)(khi[k] >> (probe_bits - 32u)) : keys[k] >> probe_bits; };
+    auto key_at = [&](uint32_t pos) -> uint64_t { return HI ? keys[vals[pos]] : keys[pos]; };
     if (threadIdx.x < 3u) s_n[threadIdx.x] = 0u;
     if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = 0u;
     __syncthreads();
@@ -544,16 +562,14 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ ke
     for (uint32_t c = 0; c < kRunItems; ++c) {
         const uint32_t k = (blockIdx.x * kRunItems + c) * 256u + threadIdx.x;
         if (k + 1u < n) {
-            const uint64_t kk = keys[k];
-            const uint64_t hi = kk >> low_bits;
-            const bool first = k == 0u || (keys[k - 1u] >> low_bits) != hi;
-            if (first && (keys[k + 1u] >> low_bits) == hi) {
+            const uint64_t hi = high(k);
+            const bool first = k == 0u || high(k - 1u) != hi;
+            if (first && high(k + 1u) == hi) {
                 // sorted by the high bits: if the body 64 places on still shares them, so do all in between
-                if (k + kRunWave < n && (keys[k + kRunWave] >> low_bits) == hi) s_long[atomicAdd(&s_n[1], 1u)] = k;
+                if (k + kRunWave < n && high(k + kRunWave) == hi) s_long[atomicAdd(&s_n[1], 1u)] = k;
                 else s_short[atomicAdd(&s_n[0], 1u)] = k;
             }
-            if (probe_bits && k + kRunProbeSpan < n && (keys[k + kRunProbeSpan] >> probe_bits) == (kk >> probe_bits))
-                s_n[2] = 1u;
+            if (probe_bits && k + kRunProbeSpan < n && coarse(k + kRunProbeSpan) == coarse(k)) s_n[2] = 1u;
         }
     }
     __syncthreads();
@@ -562,11 +578,11 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ ke
     // short runs: one wave each (the order in which the lists were filled does not matter: the runs are disjoint)
     for (uint32_t r = threadIdx.x >> 6; r < n_short; r += 4u) {
         const uint32_t start = s_short[r];
-        const uint64_t hi = keys[start] >> low_bits;
+        const uint64_t hi = high(start);
         const uint32_t pos = start + lane;
-        const bool in = pos < n && (keys[min(pos, n - 1u)] >> low_bits) == hi;   // (a run is < 64 long here)
+        const bool in = pos < n && high(min(pos, n - 1u)) == hi;   // (a run is < 64 long here)
         const uint32_t len = (uint32_t)__popcll(__ballot(in));
-        const uint64_t ki = in ? keys[pos] : ~0ull;
+        const uint64_t ki = in ? key_at(pos) : ~0ull;
         const uint32_t vi = in ? vals[pos] : 0u;
         uint32_t rank = 0;
         for (uint32_t j = 0; j < len; ++j) {
@@ -576,30 +592,35 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ ke
         }
         __builtin_amdgcn_wave_barrier();
         if (in) {
-            keys[start + rank] = ki;
+            if (!HI) run_keys[start + rank] = ki;
             vals[start + rank] = vi;
         }
     }
     // long runs: the whole workgroup, one after the other
     for (uint32_t r = 0; r < n_long; ++r) {
         const uint32_t start = s_long[r];
-        const uint64_t hi = keys[start] >> low_bits;
+        const uint64_t hi = high(start);
         uint32_t lo_s = start + kRunWave, hi_s = n;   // first position past the run: binary search
         while (lo_s < hi_s) {
             const uint32_t mid = lo_s + ((hi_s - lo_s) >> 1);
-            if ((keys[mid] >> low_bits) == hi) lo_s = mid + 1u; else hi_s = mid;
+            if (high(mid) == hi) lo_s = mid + 1u; else hi_s = mid;
         }
         const uint32_t len = lo_s - start;
         if (threadIdx.x == 0u) atomicMax(&stat[0], len);
+        if (HI) {  // the run's keys, in the run's slots of the scratch array
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) run_keys[start + i] = keys[vals[start + i]];
+            __threadfence_block();
+            __syncthreads();
+        }
         if (len > kRunCountMax) {
-            run_radix_sort(keys, vals, alt_keys, alt_vals, start, len, low_bits, s_hist, s_wcnt, s_w, &s_flag);
+            run_radix_sort(run_keys, vals, alt_keys, alt_vals, start, len, low_bits, s_hist, s_wcnt, s_w, &s_flag);
             continue;
         }
         for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-            const uint64_t ki = keys[start + i];
+            const uint64_t ki = run_keys[start + i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < len; ++j) {
-                const uint64_t kj = keys[start + j];
+                const uint64_t kj = run_keys[start + j];
                 rank += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
             }
             alt_keys[start + rank] = ki;
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *__restrict__ ke
         __threadfence_block();
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-            keys[start + i] = alt_keys[start + i];
+            run_keys[start + i] = alt_keys[start + i];
             vals[start + i] = alt_vals[start + i];
         }
         __syncthreads();
@@ -750,9 +771,14 @@ constexpr uint32_t kCellTile = 1024;                 // bodies per workgroup of 
                                                      // chain of barriers inside a workgroup, not by work)
 constexpr uint32_t kCellRows = kMaxDepth + 2;        // u32 rows of the tile table: [0] nint, [1 + d] depth d
 
+// GATHER (section 3e: the sort moved high words and indices only): `keys` are the UNSORTED keys, a body's key is
+// gathered through `order` like its position, and the sorted key array the later kernels search is written
+// here (keys_out); the neighbours' keys come from the neighbouring lanes.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void cells_a_kernel(
     const uint32_t *__restrict__ order, uint32_t n, const float4 *__restrict__ posm_in,
-    float4 *__restrict__ posm_out, const uint64_t *__restrict__ keys, int8_t *__restrict__ cpl,
+    float4 *__restrict__ posm_out, const uint64_t *__restrict__ keys, uint64_t *__restrict__ keys_out,
+    int8_t *__restrict__ cpl,
     uint32_t *__restrict__ tile_u32, Moments *__restrict__ tile_mom, uint32_t stride, uint32_t rounds,
     uint32_t *__restrict__ status) {
     __shared__ uint32_t s_hist[kCellRows];
@@ -764,22 +790,39 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
     for (uint32_t sub = 0; sub < rounds; ++sub) {
         const uint32_t k = (blockIdx.x * rounds + sub) * 256u + threadIdx.x;
         Moments item{0, 0, 0, 0};
+        uint64_t me = 0, me_prev = 0, me_next = 0;
+        uint32_t src = 0;
         if (k < n) {
-            const float4 p = posm_in[order[k]];  // sort_particles, tree.rs:564-602
+            src = order[k];
+            me = GATHER ? keys[src] : keys[k];
+        }
+        if (GATHER) {  // (outside the bounds check: every lane takes part in the shuffles)
+            const uint32_t lane = threadIdx.x & 63u;
+            me_prev = ((uint64_t)(uint32_t)__shfl_up((int)(me >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)me, 1);
+            me_next = ((uint64_t)(uint32_t)__shfl_down((int)(me >> 32), 1) << 32) | (uint32_t)__shfl_down((int)(uint32_t)me, 1);
+            if (lane == 0u && k > 0u && k < n) me_prev = keys[order[k - 1u]];
+            if (lane == 63u && k + 1u < n) me_next = keys[order[k + 1u]];
+        }
+        if (k < n) {
+            const float4 p = posm_in[src];  // sort_particles, tree.rs:564-602
             posm_out[k] = p;
             const double m = (double)p.w;
             item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
-            const uint64_t me = keys[k];
-            const int left = k > 0 ? cpl_levels(keys[k - 1], me) : -1;
+            if (GATHER) keys_out[k] = me;
+            else {
+                me_prev = k > 0 ? keys[k - 1] : 0ull;
+                me_next = k + 1 < n ? keys[k + 1] : 0ull;
+            }
+            const int left = k > 0 ? cpl_levels(me_prev, me) : -1;
             // (a lone body: the reference's root is always an internal octant -- the queue starts with the
             // root partition whatever it holds, tree.rs:463-476 -- so the body's leaf sits at depth 1)
-            const int right = k + 1 < n ? cpl_levels(me, keys[k + 1]) : (n == 1u ? 0 : -1);
+            const int right = k + 1 < n ? cpl_levels(me, me_next) : (n == 1u ? 0 : -1);
             if (k == 0) cpl[0] = -1;
             cpl[k + 1] = (int8_t)right;
             nint_sum += right > left ? (uint32_t)(right - left) : 0u;  // internal cells this body opens
             for (int d = left + 1; d <= right; ++d) atomicAdd(&s_hist[1 + d], 1u);
             atomicAdd(&s_hist[1 + (left > right ? left : right) + 1], 1u);  // its leaf
-            if (k + 1 < n && keys[k + 1] == me) collide += 1u;
+            if (k + 1 < n && me_next == me) collide += 1u;
         }
         Moments total;
         (void)block_scan_moments(item, s_wave, &total);  // fixed order inside the round
@@ -1003,9 +1046,11 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ bound_bits,
                             float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
                             uint32_t *__restrict__ child, NodeRec *__restrict__ rec, float inv_theta2) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the grid covers ~1.75 N nodes -- a uniform octree has ~1.5 N, the capacity is 4 N and the count is only
+    // known on the device: the workgroups that would find nothing to do are not launched, a deeper tree
+    // takes the loop)
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
-    if (id >= n_nodes) return;
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n_nodes; id += gridDim.x * blockDim.x) {
     const uint32_t k = node_first[id];
     const uint32_t dd = node_depth[id];
     uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1122,6 +1167,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     if (AOS) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
+    }
     }
 }
 
@@ -1951,6 +1997,7 @@ struct LetRange {
 };
 constexpr uint32_t kLetExportThreads = 1024, kLetExportRanges = 3072;  // 2 lists x 24 KiB of LDS
 constexpr uint32_t kLetReserved = 73;  // the root, its 8 children, their 64 children: fixed slots
+constexpr uint32_t kLetListOverflow = 0x80000000u;  // status[0]: a level outgrew the one-launch export's range list
 
 __device__ __forceinline__ uint32_t let_export_want(const NodeRec &r, const float (&blo)[3], const float (&bhi)[3],
                                                     bool prune, uint32_t n_nodes) {
@@ -2059,8 +2106,12 @@ __global__ __launch_bounds__(kLetExportThreads) void let_export_kernel(
                             s_list[cur ^ 1u][k] = LetRange{base, total};
                             s_n[cur ^ 1u] = k + 1u;
                         } else {
-                            atomicAdd(&status[0], 1u);  // capacity exceeded: reported by check_status
-                            base = ~0u;                 // (and none of this chunk's cells is exported with children)
+                            // the peer's segment is full (counted), or this level has more ranges than the LDS list
+                            // holds (flagged apart: the segment had room, the level-by-level export would succeed);
+                            // either way none of this chunk's cells is exported with children.  check_status reports it.
+                            if (base + total > cap) atomicAdd(&status[0], 1u);
+                            else atomicOr(&status[0], kLetListOverflow);
+                            base = ~0u;
                         }
                     }
                     s_base = base;
@@ -2764,8 +2815,8 @@ class TreeSim final : public SimBase {
         // profiles/r02_sort_experiments.txt.)
         uint32_t bits = 63;
         if (sort_mode == 1) {
-            bits = 6;
-            while ((1ull << bits) < 64ull * n) ++bits;
+            bits = sort_spare;
+            while ((1ull << bits) < ((unsigned long long)n << sort_spare)) ++bits;
             bits = std::min(63u, std::max(21u, bits));
             // a step whose fix-up met a long run (a dense core in a cube stretched by escapers) makes the next
             // steps sort more high digits (wait(): sort_boost), until the probe says they can go again
@@ -2776,21 +2827,69 @@ class TreeSim final : public SimBase {
         const uint32_t bins = 1u << W;
         const uint32_t passes = (bits + W - 1u) / W;
         const uint32_t shift0 = 63u > passes * W ? 63u - passes * W : 0u;  // the passes cover bits shift0 .. 62
+        // 3e: up to 31 sorted bits all lie in the keys' HIGH WORDS, so the passes move (high word, index) --
+        // 8-byte instead of 12-byte elements, and no identity index array to begin with -- the fix-up looks a
+        // tied body's full key up through its index, and the sorted 64-bit keys are gathered once, by
+        // cells_a_kernel beside the positions.  hs0: where the first digit sits inside the high word (three
+        // passes: bits 7..30, the same 24 key bits as without; four: the whole word, key bits 32..62).
+        const bool hi_mode = sort_hi && sort_mode == 1 && !rank_sort && W == kSortBits && passes <= 4u && bits <= 31u;
+        const uint32_t hs0 = 31u > kSortBits * passes ? 31u - kSortBits * passes : 0u;
+        uint32_t *khi[2] = {reinterpret_cast<uint32_t *>(keys[1]), reinterpret_cast<uint32_t *>(keys[1]) + n};
         if (rank_sort)
             hipLaunchKernelGGL(morton_kernel, dim3((n + kSortThreads - 1) / kSortThreads), dim3(kSortThreads), 0, stream,
                                posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u,
-                               0u, 1u);
+                               0u, 1u, (uint32_t *)nullptr);
         else  // (with the tile histograms of the first pass's digit)
             // (512 threads x half the sort's items per thread: the same tile, twice the waves per SIMD for the
             // 21 dependent levels of the key descent)
             hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(2 * kSortThreads), 0, stream, posm[s], n, bound_src,
-                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items / 2u, shift0, bins);
+                               n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items / 2u,
+                               hi_mode ? 32u + hs0 : shift0, bins, hi_mode ? khi[0] : (uint32_t *)nullptr);
         int kb = 0;
         if (rank_sort) {
             // 3c: the sorted position of every body counted in one launch
             hipLaunchKernelGGL(rank_sort_kernel, dim3((n + 63u) / 64u), dim3(64 * kRankWaves), 0, stream, keys[0], n,
                                keys[1], idx[1]);
             kb = 1;
+        } else if (hi_mode) {
+            const bool inl = sort_blocks <= kSortInlineScanBlocks;
+            for (uint32_t ps = 0; ps < passes; ++ps) {
+                const uint32_t shift = hs0 + ps * kSortBits;
+                const uint32_t *vin = ps == 0u ? (const uint32_t *)nullptr : idx[kb];
+#define NB_PASS_HI(ITEMS)                                                                                           \
+    do {                                                                                                            \
+        constexpr uint32_t TH = 2u * kSortThreads;                                                                  \
+        constexpr uint32_t IT = kSortThreads * (ITEMS) / TH;                                                        \
+        if (ps != 0u)                                                                                               \
+            hipLaunchKernelGGL((radix_hist_kernel<IT, uint32_t>), dim3(sort_blocks), dim3(TH), 0, stream,          \
+                               khi[kb], n, shift, bins, hist, sort_blocks);                                         \
+        if (inl) {                                                                                                  \
+            hipLaunchKernelGGL((radix_scatter_kernel<(int)kSortBits, TH, IT, true, uint32_t>), dim3(sort_blocks),   \
+                               dim3(TH), 0, stream, khi[kb], vin, khi[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals, \
+                               sort_blocks);                                                                        \
+        } else {                                                                                                    \
+            hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), b256, 0, stream, hist, sort_blocks, totals);            \
+            hipLaunchKernelGGL((radix_scatter_kernel<(int)kSortBits, TH, IT, false, uint32_t>), dim3(sort_blocks),  \
+                               dim3(TH), 0, stream, khi[kb], vin, khi[kb ^ 1], idx[kb ^ 1], n, shift, hist, totals, \
+                               sort_blocks);                                                                        \
+        }                                                                                                           \
+    } while (0)
+                if (sort_items == kSortItemsSmall) NB_PASS_HI(kSortItemsSmall);
+                else NB_PASS_HI(kSortItems);
+#undef NB_PASS_HI
+                kb ^= 1;
+            }
+            {   // the ties: on the sorted high words, full keys through the indices; only the indices move
+                // (scratch for a long run's keys: the moment prefixes, which cells_c_kernel writes later)
+                uint64_t *scratch = reinterpret_cast<uint64_t *>(mom_prefix);
+                const uint32_t par = build_seq & 1u;
+                hipLaunchKernelGGL((runs_fix_kernel<true>), dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256,
+                                   0, stream, khi[kb], keys[0], scratch, idx[kb], scratch + n, idx[kb ^ 1], n, 32u + hs0,
+                                   0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
+                run_stat_seq = build_seq;
+                run_stat_boost = sort_boost;
+                ++build_seq;
+            }
         } else {
             for (uint32_t ps = 0; ps < passes; ++ps) {
                 const uint32_t shift = shift0 + ps * W;
@@ -2823,15 +2922,16 @@ class TreeSim final : public SimBase {
             }
             if (shift0 || sort_boost) {  // (all 63 bits sorted: nothing to fix, but the probe still has to run)
                 const uint32_t par = build_seq & 1u;
-                hipLaunchKernelGGL(runs_fix_kernel, dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256, 0, stream,
-                                   keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0,
+                hipLaunchKernelGGL((runs_fix_kernel<false>), dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256,
+                                   0, stream, (const uint32_t *)nullptr, keys[kb], keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0,
                                    sort_boost ? std::min(62u, shift0 + W) : 0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
                 run_stat_seq = build_seq;
                 run_stat_boost = sort_boost;
                 ++build_seq;
             }
         }
-        uint64_t *skeys = keys[kb];
+        // (hi_mode: cells_a_kernel gathers the sorted keys into the buffer the high words lived in)
+        uint64_t *skeys = hi_mode ? keys[1] : keys[kb];
         order = idx[kb];
         sorted_keys = skeys;
         // 4-6a: the step's source permuted into DFS/Morton order (tree.rs:297,315-325), cells from
@@ -2842,8 +2942,12 @@ class TreeSim final : public SimBase {
         if (cell_rounds && ((size_t)n + 256 * cell_rounds) / (256 * cell_rounds) + 1 <= cell_tiles) rounds = cell_rounds;
         const uint32_t ct = (uint32_t)(((size_t)n + 1 + 256 * rounds - 1) / (256 * rounds));  // covers prefix[n] too
         const uint32_t cstride = (ct + 3u) & ~3u;  // rows of the tile table, padded to 16 bytes
-        hipLaunchKernelGGL(cells_a_kernel, dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys, cpl,
-                           tile_u32, tile_mom, cstride, rounds, status);
+        if (hi_mode)
+            hipLaunchKernelGGL((cells_a_kernel<true>), dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], keys[0], skeys,
+                               cpl, tile_u32, tile_mom, cstride, rounds, status);
+        else
+            hipLaunchKernelGGL((cells_a_kernel<false>), dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys,
+                               (uint64_t *)nullptr, cpl, tile_u32, tile_mom, cstride, rounds, status);
         uint32_t *row_total = scalars + 40;  // kCellRows words
         hipLaunchKernelGGL(cells_scan_kernel, dim3(kCellRows + 4), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
                            row_total, bound_slots);
@@ -2852,7 +2956,7 @@ class TreeSim final : public SimBase {
                            rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
         va_gathered = with_va;
         // 6: node contents
-        const uint32_t gnodes = (node_cap + 255) / 256;
+        const uint32_t gnodes = (std::min<uint64_t>(node_cap, (uint64_t)n + 3ull * (n / 4u) + 256ull) + 255) / 256;
         if (n <= kFillEagerMax)
             hipLaunchKernelGGL((fill_kernel<false, true>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
@@ -2902,7 +3006,12 @@ class TreeSim final : public SimBase {
 #undef NB_WALK
         } else if (hi > lo) {
             // cells across the lanes (section 8b): a wave walks for a group of G bodies
-            const uint32_t gsize = walk_group ? walk_group : 8u;
+            // bodies per wave: 8, or 16 where that measures faster -- wide acceptance (theta >= 0.9), and the
+            // middle sizes at theta >= 0.58 (32,768 .. 262,144 bodies: -5 .. -25 % of the walk; beyond ~400,000 the
+            // two tie, below ~24,000 and at theta 0.5 8 wins: profiles/r03_walk_experiments.txt section 4)
+            const uint32_t walked = hi - lo;
+            const uint32_t gauto = walked >= 24576u && (theta >= 0.9f || (theta >= 0.58f && walked <= 393216u)) ? 16u : 8u;
+            const uint32_t gsize = walk_group ? walk_group : gauto;
             const uint32_t per_block = kCellBlockWaves * gsize;
             const dim3 gwalk((hi - lo + per_block - 1) / per_block), bwalk(64 * kCellBlockWaves);
             // one-word stack entries when the group has 8 mask bits and every id is below 2^24
@@ -2987,6 +3096,13 @@ class TreeSim final : public SimBase {
     }
 
     int report_status(const uint32_t *st) {
+        if (st[0] & kLetListOverflow) {
+            set_error("LET export: a tree level inside one grandchild of the root is wider than the one-launch export's "
+                      "list (%u ranges of up to %u cells: a heavily clustered rank); the segments had room -- set "
+                      "tree_let_export_mode 0 (one launch per tree level) for this simulator",
+                      kLetExportRanges, kLetExportThreads);
+            return NB_ERR_UNSUPPORTED;
+        }
         if (st[0]) {
             set_error("LET export needs more than tree_let_cap = %u records for a peer (%u cells cut short)",
                       let_cap, st[0]);
@@ -3219,6 +3335,20 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_sort_hi") == 0) {  // 1: radix passes on (high word, index) where <= 31 bits are sorted (default)
+            sort_hi = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_sort_spare") == 0) {  // log2 of the cells per body at the level the radix passes resolve
+            if (value < 0 || value > 12) {
+                set_error("tree_sort_spare must be 0..12");
+                return NB_ERR_INVALID;
+            }
+            sort_spare = (uint32_t)value;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_sort_wide") == 0) {  // 1: 9-bit digits where they save a pass, 0: always 8 (default)
             sort_wide = value != 0 ? 1u : 0u;
             drop_graph();
@@ -3324,7 +3454,8 @@ class TreeSim final : public SimBase {
     uint32_t node_cap = 0, sort_blocks = 0, sort_items = kSortItems;
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
-    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1, sort_wide = 0;
+    uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1, sort_wide = 0, sort_hi = 1,
+             sort_spare = 6;
     uint32_t *tile_u32 = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations

@@ -450,6 +450,10 @@ class LetTreeSim:
 
     # -- domain set-up -------------------------------------------------------------------------
     def _adopt(self, particles: np.ndarray) -> None:
+        # a new domain cut: the export counts seen so far say nothing about it, so the next two steps
+        # read their counts on the host again before a fixed stride is planned from them
+        self._known_counts.clear()
+        self._readbacks.clear()
         order, cuts, splits, ref_bound = morton_domains(particles, self.world, with_owners=True)
         self.counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
         mine = particles[order[cuts[self.rank]:cuts[self.rank + 1]]]
@@ -505,7 +509,8 @@ class LetTreeSim:
 
     def _planned_stride(self):
         """Records per peer for this step's fixed-stride exchange, or None when the counts of two
-        steps ago are not known yet (the first steps, or right after a migration).  Every rank
+        steps ago are not known yet (the first two steps, and the two after the domains were cut anew:
+        _adopt; a migration hands over a few dozen bodies, which the stride's margin covers).  Every rank
         derives it from the same all-gathered matrix of the same step, so all ranks agree."""
         k = self.step_num - 2
         if k in self._readbacks:                     # complete by now unless the host runs > 2 steps ahead
@@ -603,6 +608,8 @@ class LetTreeSim:
 
     def wait(self) -> None:
         self.stream.synchronize()
+        self.sim.wait()   # ... and the device status words: a peer with more records than the fixed stride is
+                          # raised here (nbody.h: at wait), not at the next read-back
 
     # -- read-out ----------------------------------------------------------------------------------
     def read_local(self) -> np.ndarray:
