@@ -200,7 +200,29 @@ void morton_domains(const nb_particle *p, size_t n, int world, std::vector<uint3
     }
     order.resize(n);
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    {   // stable sort by key, on up to 8 threads: sorted chunks, then pairwise stable merges (0.6 s on one thread
+        // at 4,194,304 bodies -- start-up only, but it is the caller who waits)
+        auto less = [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; };
+        const size_t chunks = n >= (1u << 18) ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        std::vector<size_t> edge(chunks + 1);
+        for (size_t c = 0; c <= chunks; ++c) edge[c] = n * c / chunks;
+        auto run = [&](auto &&fn, size_t count) {
+            std::vector<std::thread> th;
+            for (size_t c = 1; c < count; ++c) th.emplace_back(fn, c);
+            fn((size_t)0);
+            for (auto &t : th) t.join();
+        };
+        run([&](size_t c) { std::stable_sort(order.begin() + (long)edge[c], order.begin() + (long)edge[c + 1], less); }, chunks);
+        for (size_t width = 1; width < chunks; width *= 2) {
+            const size_t pairs = (chunks + 2 * width - 1) / (2 * width);
+            run([&](size_t p) {
+                const size_t lo = 2 * width * p, mid = std::min(lo + width, chunks), hi = std::min(lo + 2 * width, chunks);
+                if (mid < hi)
+                    std::inplace_merge(order.begin() + (long)edge[lo], order.begin() + (long)edge[mid],
+                                       order.begin() + (long)edge[hi], less);
+            }, pairs);
+        }
+    }
     std::vector<uint64_t> sk(n);
     for (size_t i = 0; i < n; ++i) sk[i] = keys[order[i]];
     cuts.assign(1, 0);

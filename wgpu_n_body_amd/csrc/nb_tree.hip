@@ -39,6 +39,7 @@
 // root_width/2^21) cannot be separated (the reference would recurse until its 4N-node buffer
 // overflows); cog/mass come from binary64 prefix sums instead of a sequential fp32 sum per cell.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restric
     auto coarse = [&](uint32_t k) -> uint64_t { return HI ? (uint64_t)(khi[k] >> (probe_bits - 32u)) : keys[k] >> probe_bits; };
     auto key_at = [&](uint32_t pos) -> uint64_t { return HI ? keys[vals[pos]] : keys[pos]; };
     if (threadIdx.x < 3u) s_n[threadIdx.x] = 0u;
-    if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = stat_clear[4] = 0u;
     __syncthreads();
 #pragma unroll
     for (uint32_t c = 0; c < kRunItems; ++c) {
@@ -631,6 +632,93 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restric
         for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
             run_keys[start + i] = alt_keys[start + i];
             vals[start + i] = alt_vals[start + i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 3e. the fix-up of the high-word sort, a thread per body ----------------------------------------------
+// After the passes over (high word, index) the array is sorted by the top bits and every body is either alone
+// with its high bits or in a run of ties.  Here EVERY body finds its final place by itself: a singleton
+// copies its index across; a body in a run shorter than 64 looks left and right for the run's ends on the
+// sorted high words, fetches the full keys of the run's members through their indices and counts how many
+// come before it -- (key, place in the run) order, the stable order of the full-key sort.  The result goes OUT
+// OF PLACE (vals_out), so no body waits for another: where a quarter of the bodies sit in runs of two or
+// three -- one radix pass less than runs_fix_kernel's wave-per-run scheme could afford -- this costs what a
+// copy of the index array costs plus a few gathers.  Runs of 64 or more (clustered input) are left to the
+// workgroup that holds their first body, as in runs_fix_kernel: ranked by counting up to kRunCountMax, radix-
+// sorted beyond, and copied to vals_out.  stat / probe: as runs_fix_kernel.
+__global__ __launch_bounds__(256) void runs_rank_kernel(const uint32_t *__restrict__ khi, const uint64_t *__restrict__ keys,
+                                                        uint32_t *vals_in, uint32_t *vals_out, uint64_t *run_keys,
+                                                        uint64_t *alt_keys, uint32_t n, uint32_t low_bits,
+                                                        uint32_t probe_bits, uint32_t *__restrict__ stat,
+                                                        uint32_t *__restrict__ stat_clear) {
+    __shared__ uint32_t s_long[256 / kRunWave + 1], s_n[2];
+    __shared__ uint32_t s_hist[256], s_wcnt[4][256], s_w[4], s_flag;
+    const uint32_t hs = low_bits - 32u;
+    if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = stat_clear[4] = 0u;
+    __syncthreads();
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < n) {
+        const uint32_t hw = khi[k], hi = hw >> hs;
+        const bool left = k > 0u && (khi[k - 1u] >> hs) == hi, right = k + 1u < n && (khi[k + 1u] >> hs) == hi;
+        if (!left && !right) {
+            vals_out[k] = vals_in[k];
+        } else {
+            uint32_t s = k, e = k + 1u;  // the run [s, e), as far as it matters: up to kRunWave places either way
+            while (s > 0u && k - s < kRunWave && (khi[s - 1u] >> hs) == hi) --s;
+            while (e < n && e - s < kRunWave && (khi[e] >> hs) == hi) ++e;
+            if (e - s >= kRunWave) {  // a long run: its first body's workgroup sorts it
+                if (!left) s_long[atomicAdd(&s_n[0], 1u)] = k;
+            } else {
+                const uint32_t mine = vals_in[k];
+                const uint64_t ki = keys[mine];
+                uint32_t rank = 0u;
+                for (uint32_t j = s; j < e; ++j) {
+                    const uint64_t kj = keys[vals_in[j]];
+                    rank += (kj < ki || (kj == ki && j < k)) ? 1u : 0u;
+                }
+                vals_out[s + rank] = mine;
+            }
+        }
+        // (the probe of this kernel COUNTS: bodies whose run, with one digit less, would be a long one)
+        if (probe_bits && k + kRunWave < n && (khi[k + kRunWave] >> (probe_bits - 32u)) == (hw >> (probe_bits - 32u)))
+            atomicAdd(&s_n[1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u && s_n[1]) atomicAdd(&stat[2], s_n[1]);
+    const uint32_t n_long = s_n[0];
+    for (uint32_t r = 0; r < n_long; ++r) {
+        const uint32_t start = s_long[r];
+        const uint32_t hi = khi[start] >> hs;
+        uint32_t lo_s = start + kRunWave, hi_s = n;   // first position past the run: binary search
+        while (lo_s < hi_s) {
+            const uint32_t mid = lo_s + ((hi_s - lo_s) >> 1);
+            if ((khi[mid] >> hs) == hi) lo_s = mid + 1u; else hi_s = mid;
+        }
+        const uint32_t len = lo_s - start;
+        if (threadIdx.x == 0u) {
+            atomicMax(&stat[0], len);
+            atomicAdd(&stat[4], len);  // bodies that took this slow path
+        }
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) run_keys[start + i] = keys[vals_in[start + i]];
+        __threadfence_block();
+        __syncthreads();
+        if (len > kRunCountMax) {
+            run_radix_sort(run_keys, vals_in, alt_keys, vals_out, start, len, low_bits, s_hist, s_wcnt, s_w, &s_flag);
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) vals_out[start + i] = vals_in[start + i];
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+            const uint64_t ki = run_keys[start + i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < len; ++j) {
+                const uint64_t kj = run_keys[start + j];
+                rank += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+            }
+            vals_out[start + rank] = vals_in[start + i];
         }
         __syncthreads();
     }
@@ -2395,7 +2483,7 @@ class TreeSim final : public SimBase {
 #endif
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 128, stream));
         NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 16, stream));
-        NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 8, hipHostMallocDefault));
+        NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 12, hipHostMallocDefault));
         return write_particles(host, count);
     }
 
@@ -2813,14 +2901,24 @@ class TreeSim final : public SimBase {
         // key "tree_sort_wide": measured twice and not faster, a 9-bit scatter costs 17 instead of 13 us at
         // 2^20 bodies and the fix-up sees 30x the runs, which eats the pass saved:
         // profiles/r02_sort_experiments.txt.)
+        // How many: with the thread-per-body fix-up of the high-word sort (3e) ties are cheap, so only as many
+        // bits as leave about two bodies per cell of the resolved level (2^bits >= N / 2: 16 bits up to 131,072
+        // bodies, 24 up to 33 million -- a pass less than the 64-bit form needs, whose wave-per-run fix-up wants
+        // 1/64 body per cell: 2^bits >= 64 N).  tree_sort_spare_hi / tree_sort_spare: log2 of cells per body.
         uint32_t bits = 63;
+        bool hi_fit = false;
         if (sort_mode == 1) {
-            bits = sort_spare;
-            while ((1ull << bits) < ((unsigned long long)n << sort_spare)) ++bits;
-            bits = std::min(63u, std::max(21u, bits));
+            auto bits_for = [&](int spare) {
+                uint32_t b = 8u;
+                while (b < 63u && std::ldexp(1.0, (int)b) < std::ldexp((double)n, spare)) ++b;
+                return b;
+            };
             // a step whose fix-up met a long run (a dense core in a cube stretched by escapers) makes the next
             // steps sort more high digits (wait(): sort_boost), until the probe says they can go again
-            if (!rank_sort) bits = std::min(63u, bits + kSortBits * sort_boost);
+            const uint32_t boost = rank_sort ? 0u : kSortBits * sort_boost;
+            const uint32_t bits_hi = (sort_bits ? sort_bits : std::max(16u, bits_for(sort_spare_hi))) + boost;
+            hi_fit = sort_hi && !rank_sort && !sort_wide && bits_hi <= 31u;
+            bits = hi_fit ? bits_hi : std::min(63u, (sort_bits ? sort_bits : std::max(21u, bits_for((int)sort_spare))) + boost);
         }
         const uint32_t W = (bits + kSortWideBits - 1u) / kSortWideBits < (bits + kSortBits - 1u) / kSortBits && sort_wide
                                ? kSortWideBits : kSortBits;
@@ -2832,7 +2930,7 @@ class TreeSim final : public SimBase {
         // tied body's full key up through its index, and the sorted 64-bit keys are gathered once, by
         // cells_a_kernel beside the positions.  hs0: where the first digit sits inside the high word (three
         // passes: bits 7..30, the same 24 key bits as without; four: the whole word, key bits 32..62).
-        const bool hi_mode = sort_hi && sort_mode == 1 && !rank_sort && W == kSortBits && passes <= 4u && bits <= 31u;
+        const bool hi_mode = hi_fit && W == kSortBits && passes <= 4u;
         const uint32_t hs0 = 31u > kSortBits * passes ? 31u - kSortBits * passes : 0u;
         uint32_t *khi[2] = {reinterpret_cast<uint32_t *>(keys[1]), reinterpret_cast<uint32_t *>(keys[1]) + n};
         if (rank_sort)
@@ -2879,16 +2977,20 @@ class TreeSim final : public SimBase {
 #undef NB_PASS_HI
                 kb ^= 1;
             }
-            {   // the ties: on the sorted high words, full keys through the indices; only the indices move
+            {   // the ties: on the sorted high words, full keys through the indices; every body finds its place
+                // and the order comes out in the other index array
                 // (scratch for a long run's keys: the moment prefixes, which cells_c_kernel writes later)
                 uint64_t *scratch = reinterpret_cast<uint64_t *>(mom_prefix);
                 const uint32_t par = build_seq & 1u;
-                hipLaunchKernelGGL((runs_fix_kernel<true>), dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256,
-                                   0, stream, khi[kb], keys[0], scratch, idx[kb], scratch + n, idx[kb ^ 1], n, 32u + hs0,
-                                   0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
+                hipLaunchKernelGGL(runs_rank_kernel, dim3((n + 255u) / 256u), b256, 0, stream, khi[kb], keys[0], idx[kb],
+                                   idx[kb ^ 1], scratch, scratch + n, n, 32u + hs0,
+                                   sort_boost ? std::min(62u, 32u + hs0 + kSortBits) : 0u, scalars + 8 + par,
+                                   scalars + 8 + (par ^ 1u));
                 run_stat_seq = build_seq;
                 run_stat_boost = sort_boost;
+                run_stat_hi = true;
                 ++build_seq;
+                kb ^= 1;
             }
         } else {
             for (uint32_t ps = 0; ps < passes; ++ps) {
@@ -2927,6 +3029,7 @@ class TreeSim final : public SimBase {
                                    sort_boost ? std::min(62u, shift0 + W) : 0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
                 run_stat_seq = build_seq;
                 run_stat_boost = sort_boost;
+                run_stat_hi = false;
                 ++build_seq;
             }
         }
@@ -3067,23 +3170,26 @@ class TreeSim final : public SimBase {
     int wait() override {
         if (int rc = bind_device()) return rc;
         if (!h_status || !scalars) return SimBase::wait();
-        NB_HIP_TRY(hipMemcpyAsync(h_status, scalars + 4, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, stream));
+        NB_HIP_TRY(hipMemcpyAsync(h_status, scalars + 4, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost, stream));
         NB_HIP_TRY(hipStreamSynchronize(stream));
         adapt_sort(h_status + 4);
         return report_status(h_status);
     }
 
-    // st: {longest run, parity 0; parity 1; probe flag, parity 0; parity 1} of the last two fix-ups.
+    // st: {longest run; probe; bodies in long runs} x {parity 0, parity 1} of the last two fix-ups.
     // Speed only -- the sort's result does not depend on it -- so it does not matter which step's
     // statistics a given wait() happens to see.
     void adapt_sort(const uint32_t *st) {
         if (run_stat_seq == ~0u || run_stat_seq == run_stat_seen) return;  // no fix-up since the last look
         run_stat_seen = run_stat_seq;
-        const uint32_t par = run_stat_seq & 1u, longest = st[par], probe = st[2 + par];
+        const uint32_t par = run_stat_seq & 1u, longest = st[par], probe = st[2 + par], slow = st[4 + par];
         const uint32_t before = sort_boost;
-        if (longest > kRunBoostAbove) {
+        // one more digit: a run that is radix-sorted by one workgroup, or (high-word sort: every run of 64 or
+        // more takes a workgroup's turn) more than 1/64 of the bodies in such runs -- a disc, a dense core
+        if (longest > kRunBoostAbove || slow > n / 64u) {
             sort_boost = std::min(kSortBoostMax, run_stat_boost + (longest > 256u * kRunBoostAbove ? 2u : 1u));
-        } else if (run_stat_boost != 0u && probe == 0u && sort_boost == run_stat_boost) {
+        } else if (run_stat_boost != 0u && sort_boost == run_stat_boost &&
+                   (run_stat_hi ? probe <= n / 256u : probe == 0u)) {
             sort_boost = run_stat_boost - 1u;  // with one digit less the runs would still be short
         }
         if (sort_boost != before) drop_graph();  // the captured launch sequence has the old number of passes
@@ -3340,6 +3446,24 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_sort_bits") == 0) {  // the high key bits the radix passes sort (0: by tree_sort_spare)
+            if (value < 0 || value > 63 || (value > 0 && value < 8)) {
+                set_error("tree_sort_bits must be 0 or 8..63");
+                return NB_ERR_INVALID;
+            }
+            sort_bits = (uint32_t)value;
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_sort_spare_hi") == 0) {  // ... for the high-word sort (default -1: two bodies per cell)
+            if (value < -8 || value > 12) {
+                set_error("tree_sort_spare_hi must be -8..12");
+                return NB_ERR_INVALID;
+            }
+            sort_spare_hi = value;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_sort_spare") == 0) {  // log2 of the cells per body at the level the radix passes resolve
             if (value < 0 || value > 12) {
                 set_error("tree_sort_spare must be 0..12");
@@ -3455,7 +3579,8 @@ class TreeSim final : public SimBase {
     bool count_visits = false, use_graph = false;
     uint32_t walk_bpw = 0;
     uint32_t walk_mode = 1, walk_group = 0, sort_mode = 1, cell_rounds = 0, walk_packed = 1, sort_wide = 0, sort_hi = 1,
-             sort_spare = 6;
+             sort_spare = 6, sort_bits = 0;
+    int sort_spare_hi = -1;
     uint32_t *tile_u32 = nullptr;
     bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
@@ -3481,6 +3606,7 @@ class TreeSim final : public SimBase {
     // extra high digits the radix passes cover (adapt_sort), and the fix-up launch its statistics belong to
     static constexpr uint32_t kSortBoostMax = 6;
     uint32_t sort_boost = 0, build_seq = 0, run_stat_seq = ~0u, run_stat_seen = ~0u, run_stat_boost = 0;
+    bool run_stat_hi = false;
     hipEvent_t *time_walk = nullptr;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
