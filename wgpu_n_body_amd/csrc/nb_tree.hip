@@ -1121,8 +1121,13 @@ __device__ __forceinline__ uint32_t lower_bound_key(const uint64_t *keys, uint32
 // demand): also the reference's Octant fields -- cog, body count, the 8-entry children table
 // indexed by octant -- which cost two more dependent loads per child and 52 B of stores per node.
 constexpr uint32_t kFillEagerMax = 262144;  // bodies up to which fill_kernel fetches speculatively
+// ... and from which it does again, all but the moment prefix: there the kernel waits out a dozen dependent loads
+// per cell with every CU busy, and the probes of the run search and the candidate children sit in the lines the
+// cell reads anyway (build 0.625 -> 0.605 ms at 4,000,000 bodies, 2.65 -> 2.63 at 16,777,216; 0.179 -> 0.181 at 2^20)
+constexpr uint32_t kFillEagerAgainFrom = 2097152;
 
-template <bool AOS, bool EAGER>
+// EAGER_MOM: also the first moment prefix ahead of the search (small problems only: see below)
+template <bool AOS, bool EAGER, bool EAGER_MOM = EAGER>
 __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint32_t n_cap,
                             const uint32_t *__restrict__ n_nodes_p,
                             const uint32_t *__restrict__ node_first,
@@ -1165,7 +1170,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         const uint32_t slot_k = (EAGER || opens_next) ? int_slot[k] : 0u;
         const uint32_t leaf_k = (EAGER || !opens_next) ? leaf_id[k] : 0u;
         Moments a{0, 0, 0, 0};
-        if (EAGER) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
+        if (EAGER_MOM) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
                                 // fetched apart it has left the L2 by then: 185 -> 241 MB of HBM reads at 2^20)
         // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
         uint32_t end = n;
@@ -1231,7 +1236,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             }
         }
         // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
-        if (!EAGER) a = mom[k];
+        if (!EAGER_MOM) a = mom[k];
         const Moments b2 = mom[end];
         const double m = b2.m - a.m;
         const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
@@ -3062,6 +3067,10 @@ class TreeSim final : public SimBase {
         const uint32_t gnodes = (std::min<uint64_t>(node_cap, (uint64_t)n + 3ull * (n / 4u) + 256ull) + 255) / 256;
         if (n <= kFillEagerMax)
             hipLaunchKernelGGL((fill_kernel<false, true>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
+                               node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
+        else if (n >= kFillEagerAgainFrom)
+            hipLaunchKernelGGL((fill_kernel<false, true, false>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
                                mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
         else
