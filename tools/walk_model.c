@@ -180,6 +180,53 @@ static void walk_group_c2(uint32_t lo, int nb, int G, float theta2, int batch, C
 
 static void walk_group_c(uint32_t lo, int G, float theta2, int batch, CStats *st) { walk_group_c2(lo, G, G, theta2, batch, st); }
 
+// ---- scheme D: TWO groups per wave, 32 lanes each (own stack, own 8 bodies as per-lane operands) --------
+// One iteration = one batch instruction stream for the wave: each half pops up to 32 of its group's cells.
+// refill = 1: a half whose group is finished takes the next group from a queue (dynamic); 0: the wave ends
+// when both of its two groups have.  Returns the iterations (batches) spent; `cells` the lanes that held a cell.
+typedef struct { CEnt st[1 << 14]; int sp; uint32_t lo; int live; } Half;
+static void half_start(Half *h, uint32_t lo) { h->sp = 0; h->st[h->sp++] = (CEnt){0, 0xffu}; h->lo = lo; h->live = 1; }
+static int half_step(Half *h, float theta2, int width) {   // one batch of this half: returns the cells popped
+    const int c = h->sp < width ? h->sp : width;
+    CEnt cur[64];
+    memcpy(cur, h->st + h->sp - c, sizeof(CEnt) * c);
+    h->sp -= c;
+    for (int l = 0; l < c; ++l) {
+        const Rec *r = &rec[cur[l].id];
+        uint32_t open = 0;
+        for (int b = 0; b < 8; ++b) {
+            if (!((cur[l].mask >> b) & 1)) continue;
+            const f4 p = kp[h->lo + b].p;
+            const float dx = r->cogm.x - p.x, dy = r->cogm.y - p.y, dz = r->cogm.z - p.z;
+            const float r2 = dz * dz + (dy * dy + dx * dx);
+            if (!(r->ssize2 < theta2 * r2)) open |= 1u << b;
+        }
+        if (open)
+            for (uint32_t k = 0; k < r->count; ++k) h->st[h->sp++] = (CEnt){r->first + k, open};
+    }
+    if (h->sp == 0) h->live = 0;
+    return c;
+}
+static void scheme_d(uint32_t first_body, uint32_t n_groups, float theta2, int refill, double *iters, double *cells) {
+    static _Thread_local Half ha, hb;
+    uint32_t next = 0;
+    *iters = 0; *cells = 0;
+    while (next < n_groups || ha.live || hb.live) {
+        if (!ha.live && !hb.live && !refill) {   // a fresh wave: two groups
+            if (next < n_groups) half_start(&ha, first_body + 8 * next++);
+            if (next < n_groups) half_start(&hb, first_body + 8 * next++);
+        }
+        if (refill) {
+            if (!ha.live && next < n_groups) half_start(&ha, first_body + 8 * next++);
+            if (!hb.live && next < n_groups) half_start(&hb, first_body + 8 * next++);
+        }
+        if (!ha.live && !hb.live) break;
+        *iters += 1;
+        if (ha.live) *cells += half_step(&ha, theta2, 32);
+        if (hb.live) *cells += half_step(&hb, theta2, 32);
+    }
+}
+
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atol(argv[1]) : 1u << 20;
     const float theta = argc > 2 ? (float)atof(argv[2]) : 0.5f;
@@ -299,6 +346,14 @@ int main(int argc, char **argv) {
         }
         printf(" groups %.0f mean size %.2f; pair-instr per 64 bodies %.0f (batches per 64 bodies %.1f)\n", ngroups, nbodies / ngroups,
                tot.pairs / 64 / nbodies * 64, tot.batches / nbodies * 64);
+    }
+    printf("\nscheme D: two groups per wave, 32 lanes each (iterations = batch instruction streams per 64 bodies)\n");
+    for (int refill = 0; refill < 2; ++refill) {
+        double it = 0, ce = 0;
+        const uint32_t groups = 8192;
+        scheme_d(n / 3, groups, theta * theta, refill, &it, &ce);
+        printf(" %s: batches per 64 bodies %.1f (scheme C, G = 8: 8 x batches/group above), lane fill %.3f\n",
+               refill ? "a finished half takes the next group" : "the wave ends when both groups have", it / groups * 8, ce / (it * 64));
     }
     return 0;
 }
