@@ -224,6 +224,23 @@ def native_extra(nb, np, what, device_ids, steps, warmup):
     raise ValueError(what)
 
 
+def run_extras_child(gpus, steps, warmup, limit_s=300):
+    """`bench.py --gpus N --host native --extras-only` as a child process -> its dict, or {"error": ...}."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(gpus), "--steps", str(steps), "--warmup", str(warmup),
+           "--host", "native", "--extras-only"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the one-process runner did not finish within {limit_s} s (child process killed)"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"child exit {p.returncode}: {(p.stderr or p.stdout)[-400:]}"}
+    return json.loads(lines[-1])
+
+
 def hbm_traffic_from_profile(n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/*_pmc_summary.json, collected as MI355X_MICROARCH.md prescribes); null if the
@@ -253,6 +270,8 @@ def main():
     ap.add_argument("--no-tree", action="store_true", help="skip the Barnes-Hut legs (extra keys of the JSON line)")
     ap.add_argument("--no-criterion", action="store_true", help="skip the reference's criterion rows")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: skip native_host / config3 / config4")
+    ap.add_argument("--extras-only", action="store_true",
+                    help="(internal) print only the one-process runner's extra keys for --gpus N, as JSON")
     ap.add_argument("--variant", type=int, default=None, help="all-pairs kernel variant override")
     args = ap.parse_args()
 
@@ -262,6 +281,16 @@ def main():
 
     import wgpu_n_body_amd as nb
     from wgpu_n_body_amd.sharded import ShardedNaiveSim
+
+    if args.extras_only:
+        # the child process of a torchrun rank 0 (below): the one-process runner on the N devices, nothing else
+        same = os.environ.get("NB_BENCH_SAME_DEVICE") == "1"
+        ids = [0] * args.gpus if same else list(range(args.gpus))
+        out = {"native_host": native_extra(nb, np, "headline", ids, args.steps, max(args.warmup, 20)),
+               "config3": native_extra(nb, np, "config3", ids, 20, 5),
+               "config4": native_extra(nb, np, "config4", ids, 20, 5)}
+        print(json.dumps(out), flush=True)
+        return
 
     native = args.host == "native"
     world = 1 if native else int(os.environ.get("WORLD_SIZE", "1"))
@@ -471,12 +500,17 @@ def main():
                                               with_cpu=not args.no_cpu_baseline)
             out["tree_4m_theta075_headless"] = tree_leg(nb, np, 4000000, 0.75, 0, 20, local_rank, 20)
         if n_gpus > 1 and not args.no_extras:
-            # the other ranks' processes are parked at a host-side barrier below: their GPUs are idle
-            if not native:
-                out["native_host"] = native_extra(nb, np, "headline", device_ids, K, max(W, 20))
-            out["config3_262144_allpairs"] = {"rccl_host": config3_rccl,
-                                              "native_host": native_extra(nb, np, "config3", device_ids, 20, 5)}
-            out["config4_4m_let_theta05"] = {"native_host": native_extra(nb, np, "config4", device_ids, 20, 5)}
+            if native:
+                ex = {"config3": native_extra(nb, np, "config3", device_ids, 20, 5),
+                      "config4": native_extra(nb, np, "config4", device_ids, 20, 5)}
+            else:
+                # The other ranks' processes are parked at a host-side barrier below: their GPUs are idle.  The
+                # one-process runner has never met two real devices: it runs in a CHILD process with a time limit,
+                # so that a fault or a hang there costs its keys and not the line.
+                ex = run_extras_child(args.gpus, K, W)
+                out["native_host"] = ex.get("native_host", ex)
+            out["config3_262144_allpairs"] = {"rccl_host": config3_rccl, "native_host": ex.get("config3", ex)}
+            out["config4_4m_let_theta05"] = {"native_host": ex.get("config4", ex)}
         print(json.dumps(out), flush=True)
 
     if world > 1:

@@ -12,8 +12,13 @@
 //   2 morton_kernel       63-bit key per body by the reference's own float descent:
 //                         digit = (x>cx) | (y>cy)<<1 | (z>cz)<<2 with strict '>',
 //                         centre += +-width/4, width /= 2   (21 levels)        tree.rs:549-562
-//   3 radix sort          8 passes x 8 bits, (key, index) pairs: per-tile digit histogram in
-//                         LDS, per-bin scan over the tiles, stable scatter ranked with wave ballots
+//   3 sort                stable, by (key, index).  Radix passes of 8 bits (per-tile digit histogram in
+//                         LDS, per-bin scan over the tiles, stable scatter ranked with wave ballots)
+//                         over the HIGH digits only -- 2 or 3 passes on (high word of the key, index)
+//                         pairs, 3e -- then a fix-up of the bodies that tie there (runs_rank_kernel:
+//                         a thread per body; runs_fix_kernel for the 64-bit form, 3d); the whole sort
+//                         in one launch by counting up to 16,384 bodies (3c); 8 passes over the
+//                         whole key as the cross-check (tuning key tree_sort_mode 0)
 //   4-6a cells_a/scan/c   bodies into sorted order = the reference's DFS order (tree.rs:564-602);
 //                         a cell at depth d exists for every key-prefix run: body k opens the
 //                         internal cells of depths (cpl[k-1], cpl[k]] and owns one leaf at depth
@@ -31,8 +36,10 @@
 //                         body applies ITS OWN acceptance test size/dist < theta to exactly the
 //                         cells of the reference's per-thread walk (visit counts equal the
 //                         oracle's), in a different order of summation (fp32 rounding).
-//                         8b walk_cells_kernel (default): a wave walks for 8 bodies held in
-//                         scalars, its 64 lanes hold 64 cells of the traversal frontier.
+//                         8b walk_cells_kernel (default): a wave walks for 8 (or 16) bodies held in
+//                         scalars, its 64 lanes hold 64 cells of the traversal frontier; the test
+//                         compares the cell's stored acceptance radius^2 = size^2 / theta^2 with
+//                         r^2, the accumulation runs under exec = the lanes that take the cell.
 //                         8  walk_kernel: a wave walks for 64 bodies, one cell at a time.
 //
 // Deviations, all documented in DESIGN.md: bodies whose 63-bit keys collide (closer than
@@ -537,25 +544,17 @@ __device__ void run_radix_sort(uint64_t *keys, uint32_t *vals, uint64_t *alt_key
 // stat[0]: the longest run met (atomicMax; the launch of the step before zeroed it: stat_clear = the word
 // of the other parity).  stat[2], with probe_bits != 0: set if some run of keys that tie on all but their low
 // probe_bits bits is longer than kRunProbeSpan -- what the fix-up would meet with one high digit less.
-//
-// HI (section 3e: the passes sorted 32-bit high words paired with indices; low_bits >= 32): the runs are
-// found on the sorted high words `khi`, a body's full key is keys[vals[position]] -- the unsorted keys,
-// gathered only for the few bodies inside runs -- and only `vals` is permuted: the high word of a body is the
-// same anywhere in its run's bits that matter.  A long run's keys are gathered into `run_keys` first
-// (scratch, indexed like the run) and sorted there beside the indices.  !HI: `keys` is the sorted key array
-// itself, permuted in place together with `vals`; run_keys = keys.
-template <bool HI>
-__global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restrict__ khi, const uint64_t *keys,
-                                                       uint64_t *run_keys, uint32_t *__restrict__ vals,
+// (The high-word sort has its own fix-up, a thread per body: runs_rank_kernel, section 3e.)
+__global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *keys, uint32_t *__restrict__ vals,
                                                        uint64_t *__restrict__ alt_keys, uint32_t *__restrict__ alt_vals,
                                                        uint32_t n, uint32_t low_bits, uint32_t probe_bits,
                                                        uint32_t *__restrict__ stat, uint32_t *__restrict__ stat_clear) {
     __shared__ uint32_t s_short[256 * kRunItems], s_long[256 * kRunItems / kRunWave + 1], s_n[3];
     __shared__ uint32_t s_hist[256], s_wcnt[4][256], s_w[4], s_flag;
     // the bits a run ties on, and the coarser ones the probe looks at
-    auto high = [&](uint32_t k) -> uint64_t { return HI ? (uint64_t)(khi[k] >> (low_bits - 32u)) : keys[k] >> low_bits; };
-    auto coarse = [&](uint32_t k) -> uint64_t { return HI ? (uint64_t)(khi[k] >> (probe_bits - 32u)) : keys[k] >> probe_bits; };
-    auto key_at = [&](uint32_t pos) -> uint64_t { return HI ? keys[vals[pos]] : keys[pos]; };
+    auto high = [&](uint32_t k) -> uint64_t { return keys[k] >> low_bits; };
+    auto coarse = [&](uint32_t k) -> uint64_t { return keys[k] >> probe_bits; };
+    uint64_t *const run_keys = keys;
     if (threadIdx.x < 3u) s_n[threadIdx.x] = 0u;
     if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = stat_clear[4] = 0u;
     __syncthreads();
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restric
         const uint32_t pos = start + lane;
         const bool in = pos < n && high(min(pos, n - 1u)) == hi;   // (a run is < 64 long here)
         const uint32_t len = (uint32_t)__popcll(__ballot(in));
-        const uint64_t ki = in ? key_at(pos) : ~0ull;
+        const uint64_t ki = in ? keys[pos] : ~0ull;
         const uint32_t vi = in ? vals[pos] : 0u;
         uint32_t rank = 0;
         for (uint32_t j = 0; j < len; ++j) {
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restric
         }
         __builtin_amdgcn_wave_barrier();
         if (in) {
-            if (!HI) run_keys[start + rank] = ki;
+            keys[start + rank] = ki;
             vals[start + rank] = vi;
         }
     }
@@ -608,11 +607,6 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(const uint32_t *__restric
         }
         const uint32_t len = lo_s - start;
         if (threadIdx.x == 0u) atomicMax(&stat[0], len);
-        if (HI) {  // the run's keys, in the run's slots of the scratch array
-            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) run_keys[start + i] = keys[vals[start + i]];
-            __threadfence_block();
-            __syncthreads();
-        }
         if (len > kRunCountMax) {
             run_radix_sort(run_keys, vals, alt_keys, alt_vals, start, len, low_bits, s_hist, s_wcnt, s_w, &s_flag);
             continue;
@@ -1144,123 +1138,123 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     // takes the loop)
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n_nodes; id += gridDim.x * blockDim.x) {
-    const uint32_t k = node_first[id];
-    const uint32_t dd = node_depth[id];
-    uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
-        const float4 p = posm[k];
-        if (AOS) {
-            cogm[id] = p;
-            bodies[id] = 1;
-            ch[0] = order[k];  // tree.rs:532
-        }
-        rec[id] = NodeRec{p, 0u, 0u, k, -1.0f};  // walk: a leaf knows its body's sorted position
-    } else {
-        const uint32_t d = dd;
-        const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
-        // (Small problems are bound by this kernel's chain of dependent loads, not by its work: what
-        // depends only on k is fetched together and, EAGER, the first steps of the search and the
-        // eight candidate children likewise -- 6 loads deep instead of ~15: 11.6 -> 9.8 us at 16,384
-        // bodies.  At 2^20 bodies the kernel is bound by HBM traffic and the speculative loads cost
-        // 6 us: not EAGER there.)
-        const uint64_t key_k = keys[k];
-        const int left = cpl[k], right = cpl[k + 1];
-        // (only one of the two is needed: both are fetched ahead only where latency, not traffic, binds)
-        const bool opens_next = (int)d + 1 <= right;  // body k also opens the cell one level down
-        const uint32_t slot_k = (EAGER || opens_next) ? int_slot[k] : 0u;
-        const uint32_t leaf_k = (EAGER || !opens_next) ? leaf_id[k] : 0u;
-        Moments a{0, 0, 0, 0};
-        if (EAGER_MOM) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
-                                // fetched apart it has left the L2 by then: 185 -> 241 MB of HBM reads at 2^20)
-        // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
-        uint32_t end = n;
-        if (d != 0) {
-            const uint64_t limit = ((key_k >> shift) + 1ull) << shift;  // first key past the cell
-            uint32_t lo_s = k + 1u, off = 1u;
-            if (EAGER) {
-                uint64_t probe[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) probe[q] = keys[min(k + (1u << q), n - 1u)];  // k+1, k+2, k+4, k+8
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (off == (1u << q) && k + off < n && probe[q] < limit) {
+        const uint32_t k = node_first[id];
+        const uint32_t dd = node_depth[id];
+        uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
+            const float4 p = posm[k];
+            if (AOS) {
+                cogm[id] = p;
+                bodies[id] = 1;
+                ch[0] = order[k];  // tree.rs:532
+            }
+            rec[id] = NodeRec{p, 0u, 0u, k, -1.0f};  // walk: a leaf knows its body's sorted position
+        } else {
+            const uint32_t d = dd;
+            const uint32_t shift = 3u * (uint32_t)(kLevels - d);  // bits below the depth-d prefix
+            // (Small problems are bound by this kernel's chain of dependent loads, not by its work: what
+            // depends only on k is fetched together and, EAGER, the first steps of the search and the
+            // eight candidate children likewise -- 6 loads deep instead of ~15: 11.6 -> 9.8 us at 16,384
+            // bodies.  At 2^20 bodies the kernel is bound by HBM traffic and the speculative loads cost
+            // 6 us: not EAGER there.)
+            const uint64_t key_k = keys[k];
+            const int left = cpl[k], right = cpl[k + 1];
+            // (only one of the two is needed: both are fetched ahead only where latency, not traffic, binds)
+            const bool opens_next = (int)d + 1 <= right;  // body k also opens the cell one level down
+            const uint32_t slot_k = (EAGER || opens_next) ? int_slot[k] : 0u;
+            const uint32_t leaf_k = (EAGER || !opens_next) ? leaf_id[k] : 0u;
+            Moments a{0, 0, 0, 0};
+            if (EAGER_MOM) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
+                                    // fetched apart it has left the L2 by then: 185 -> 241 MB of HBM reads at 2^20)
+            // end of the cell's run: galloping search from k (most cells hold a handful of bodies)
+            uint32_t end = n;
+            if (d != 0) {
+                const uint64_t limit = ((key_k >> shift) + 1ull) << shift;  // first key past the cell
+                uint32_t lo_s = k + 1u, off = 1u;
+                if (EAGER) {
+                    uint64_t probe[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) probe[q] = keys[min(k + (1u << q), n - 1u)];  // k+1, k+2, k+4, k+8
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (off == (1u << q) && k + off < n && probe[q] < limit) {
+                            lo_s = k + off + 1u;
+                            off <<= 1;
+                        }
+                    }
+                }
+                if (!EAGER || off == 16u) {
+                    while (k + off < n && keys[k + off] < limit) {
                         lo_s = k + off + 1u;
                         off <<= 1;
                     }
                 }
+                end = lower_bound_key(keys, lo_s, min(k + off, n), limit);
             }
-            if (!EAGER || off == 16u) {
-                while (k + off < n && keys[k + off] < limit) {
-                    lo_s = k + off + 1u;
-                    off <<= 1;
-                }
+            if (AOS) bodies[id] = end - k;
+            // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
+            // (nodes of one depth are numbered in key order), starting with body k's own child
+            uint32_t f;
+            if (opens_next) {
+                const uint32_t slot = slot_k + (d - (uint32_t)(left + 1) + 1u);
+                f = slot < n_cap ? int_id[slot] : ~0u;
+            } else {
+                f = leaf_k;
             }
-            end = lower_bound_key(keys, lo_s, min(k + off, n), limit);
-        }
-        if (AOS) bodies[id] = end - k;
-        // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
-        // (nodes of one depth are numbered in key order), starting with body k's own child
-        uint32_t f;
-        if (opens_next) {
-            const uint32_t slot = slot_k + (d - (uint32_t)(left + 1) + 1u);
-            f = slot < n_cap ? int_id[slot] : ~0u;
-        } else {
-            f = leaf_k;
-        }
-        const uint32_t lim = min(depth_base[d + 2], n_nodes);  // end of the depth-(d+1) ids
-        uint32_t first = 0, cnt = 0;
-        if (!EAGER) {
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t cid = f + j;
-                if (f == ~0u || cid >= lim) break;
-                const uint32_t kc = node_first[cid];
-                if (j > 0 && kc >= end) break;
-                if (AOS) ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
-                if (cnt == 0u) first = cid;
-                ++cnt;
-            }
-        } else if (f != ~0u) {
-            uint32_t kc[8];
-#pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) kc[j] = node_first[min(f + j, n_nodes - 1u)];
-            bool more = true;
-#pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) {
-                const uint32_t cid = f + j;
-                more = more && cid < lim && (j == 0u || kc[j] < end);
-                if (more) {
-                    if (AOS) ch[(uint32_t)(keys[kc[j]] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+            const uint32_t lim = min(depth_base[d + 2], n_nodes);  // end of the depth-(d+1) ids
+            uint32_t first = 0, cnt = 0;
+            if (!EAGER) {
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t cid = f + j;
+                    if (f == ~0u || cid >= lim) break;
+                    const uint32_t kc = node_first[cid];
+                    if (j > 0 && kc >= end) break;
+                    if (AOS) ch[(uint32_t)(keys[kc] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
                     if (cnt == 0u) first = cid;
                     ++cnt;
                 }
+            } else if (f != ~0u) {
+                uint32_t kc[8];
+    #pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) kc[j] = node_first[min(f + j, n_nodes - 1u)];
+                bool more = true;
+    #pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint32_t cid = f + j;
+                    more = more && cid < lim && (j == 0u || kc[j] < end);
+                    if (more) {
+                        if (AOS) ch[(uint32_t)(keys[kc[j]] >> (shift - 3u)) & 7u] = cid;  // octant = the key digit of level d
+                        if (cnt == 0u) first = cid;
+                        ++cnt;
+                    }
+                }
+            }
+            // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
+            if (!EAGER_MOM) a = mom[k];
+            const Moments b2 = mom[end];
+            const double m = b2.m - a.m;
+            const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
+                                    (float)((b2.z - a.z) / m), (float)m};
+            if (AOS) cogm[id] = q;
+            // children are allocated contiguously in octant order (tree.rs:517-519), so the walk
+            // only needs the first child's id and how many there are
+            // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
+            // children were not all stored is walked as a single body of the cell's mass
+            // ... and children always carry larger ids than their parent (breadth-first numbering), which
+            // is what lets the walk terminate without a visit budget: enforce it here
+            if (cnt == 0u || first + cnt > n_nodes || first <= id) {
+                rec[id] = NodeRec{q, 0u, 0u, ~0u, -1.0f};
+            } else {
+                const float root_width = __uint_as_float(*bound_bits) * 2.0f;
+                float size2 = root_width * root_width;
+                for (uint32_t l = 0; l < d; ++l) size2 *= 0.25f;  // exact: the width halves per level
+                rec[id] = NodeRec{q, first, cnt, ~0u, size2 * inv_theta2};
             }
         }
-        // mass and centre of gravity of the run [k, end)   (tree.rs:486-505)
-        if (!EAGER_MOM) a = mom[k];
-        const Moments b2 = mom[end];
-        const double m = b2.m - a.m;
-        const float4 q = float4{(float)((b2.x - a.x) / m), (float)((b2.y - a.y) / m),
-                                (float)((b2.z - a.z) / m), (float)m};
-        if (AOS) cogm[id] = q;
-        // children are allocated contiguously in octant order (tree.rs:517-519), so the walk
-        // only needs the first child's id and how many there are
-        // a tree that outgrew its 4N capacity (status[1]) keeps the walk in bounds: a cell whose
-        // children were not all stored is walked as a single body of the cell's mass
-        // ... and children always carry larger ids than their parent (breadth-first numbering), which
-        // is what lets the walk terminate without a visit budget: enforce it here
-        if (cnt == 0u || first + cnt > n_nodes || first <= id) {
-            rec[id] = NodeRec{q, 0u, 0u, ~0u, -1.0f};
-        } else {
-            const float root_width = __uint_as_float(*bound_bits) * 2.0f;
-            float size2 = root_width * root_width;
-            for (uint32_t l = 0; l < d; ++l) size2 *= 0.25f;  // exact: the width halves per level
-            rec[id] = NodeRec{q, first, cnt, ~0u, size2 * inv_theta2};
+        if (AOS) {
+    #pragma unroll
+            for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
         }
-    }
-    if (AOS) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) child[(size_t)id * 8 + c] = ch[c];
-    }
     }
 }
 
@@ -3029,8 +3023,8 @@ class TreeSim final : public SimBase {
             }
             if (shift0 || sort_boost) {  // (all 63 bits sorted: nothing to fix, but the probe still has to run)
                 const uint32_t par = build_seq & 1u;
-                hipLaunchKernelGGL((runs_fix_kernel<false>), dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256,
-                                   0, stream, (const uint32_t *)nullptr, keys[kb], keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0,
+                hipLaunchKernelGGL(runs_fix_kernel, dim3((n + 256u * kRunItems - 1u) / (256u * kRunItems)), b256,
+                                   0, stream, keys[kb], idx[kb], keys[kb ^ 1], idx[kb ^ 1], n, shift0,
                                    sort_boost ? std::min(62u, shift0 + W) : 0u, scalars + 8 + par, scalars + 8 + (par ^ 1u));
                 run_stat_seq = build_seq;
                 run_stat_boost = sort_boost;
