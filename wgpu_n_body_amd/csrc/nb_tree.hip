@@ -76,6 +76,62 @@ __device__ __forceinline__ float drift(float x, float v, float dt) {
     return x + v * dt;  // tree.wgsl:106
 }
 
+// ---- wave-level scans by DPP (no LDS round trip) ---------------------------------------------------
+#define NB_DPP(old, src, ctrl, row_mask) \
+    ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (row_mask), 0xf, false))
+
+// inclusive prefix sum over the 64 lanes (row_shr within the 16-lane rows, then the row totals)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
+    x += NB_DPP(0, x, 0x111, 0xf);  // row_shr:1
+    x += NB_DPP(0, x, 0x112, 0xf);  // row_shr:2
+    x += NB_DPP(0, x, 0x114, 0xf);  // row_shr:4
+    x += NB_DPP(0, x, 0x118, 0xf);  // row_shr:8
+    x += NB_DPP(0, x, 0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+    x += NB_DPP(0, x, 0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+
+// minimum / maximum over the 64 lanes (the same DPP steps; a lane without a source keeps its own value): in lane 63
+__device__ __forceinline__ int wave_min_to_lane63(int v) {
+    uint32_t x = (uint32_t)v;
+#define NB_STEPM(ctrl, row_mask) x = (uint32_t)min((int)x, (int)NB_DPP(x, x, ctrl, row_mask))
+    NB_STEPM(0x111, 0xf); NB_STEPM(0x112, 0xf); NB_STEPM(0x114, 0xf); NB_STEPM(0x118, 0xf);
+    NB_STEPM(0x142, 0xa); NB_STEPM(0x143, 0xc);
+#undef NB_STEPM
+    return (int)x;
+}
+__device__ __forceinline__ int wave_max_to_lane63(int v) {
+    uint32_t x = (uint32_t)v;
+#define NB_STEPM(ctrl, row_mask) x = (uint32_t)max((int)x, (int)NB_DPP(x, x, ctrl, row_mask))
+    NB_STEPM(0x111, 0xf); NB_STEPM(0x112, 0xf); NB_STEPM(0x114, 0xf); NB_STEPM(0x118, 0xf);
+    NB_STEPM(0x142, 0xa); NB_STEPM(0x143, 0xc);
+#undef NB_STEPM
+    return (int)x;
+}
+
+// ... of binary64 values (the moment sums): the two halves move by DPP, the add is a v_add_f64.  Lanes without a
+// source in a step add +0.0.  Twelve VALU instructions per step instead of two LDS-crossbar shuffles
+// (ds_bpermute) and their ~60-cycle round trip: the scans of cells_a / cells_c were chains of those.
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    uint32_t lo = (uint32_t)__double_as_longlong(v), hi = (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32);
+#define NB_STEP64(ctrl, row_mask)                                                                        \
+    {                                                                                                    \
+        const uint32_t l2 = NB_DPP(0, lo, ctrl, row_mask), h2 = NB_DPP(0, hi, ctrl, row_mask);           \
+        const double s = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) +        \
+                         __longlong_as_double((long long)(((unsigned long long)h2 << 32) | l2));         \
+        lo = (uint32_t)__double_as_longlong(s);                                                          \
+        hi = (uint32_t)((unsigned long long)__double_as_longlong(s) >> 32);                              \
+    }
+    NB_STEP64(0x111, 0xf);
+    NB_STEP64(0x112, 0xf);
+    NB_STEP64(0x114, 0xf);
+    NB_STEP64(0x118, 0xf);
+    NB_STEP64(0x142, 0xa);
+    NB_STEP64(0x143, 0xc);
+#undef NB_STEP64
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---- 1. bound -----------------------------------------------------------------------------------
 // max over bodies and axes of |coord|, never below 1.0 (rayon reduce identity [1.0;3],
 // tree.rs:427-433).  Non-negative floats order like their bit patterns -> atomicMax on u32.
@@ -208,11 +264,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t *__restrict__ hi
     for (uint32_t base = 0; base < nblocks; base += 256) {
         const uint32_t i = base + threadIdx.x;
         const uint32_t v = i < nblocks ? row[i] : 0u;
-        uint32_t x = v;  // inclusive scan within the wave
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
-        }
+        const uint32_t x = wave_scan_u32(v);  // inclusive scan within the wave
         if (lane == 63) s_wave[wave] = x;
         __syncthreads();
         uint32_t off = s_carry;
@@ -228,11 +280,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t *__restrict__ hi
 // exclusive scan over the workgroup of one value per thread
 __device__ __forceinline__ uint32_t sort_scan_block(uint32_t v, uint32_t *s_w) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
-        if ((int)lane >= o) x += y;
-    }
+    const uint32_t x = wave_scan_u32(v);
     if (lane == 63) s_w[wave] = x;
     __syncthreads();
     uint32_t off = 0;
@@ -776,11 +824,7 @@ __device__ __forceinline__ int cpl_levels(uint64_t a, uint64_t b) {
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *s_wave,
                                                              uint32_t *total) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
-        if ((int)lane >= o) x += y;
-    }
+    const uint32_t x = wave_scan_u32(v);
     if (lane == 63) s_wave[wave] = x;
     __syncthreads();
     uint32_t off = 0;
@@ -825,11 +869,7 @@ __device__ __forceinline__ Moments operator+(const Moments &a, const Moments &b)
 }
 __device__ __forceinline__ Moments block_scan_moments(Moments v, Moments *s_wave, Moments *total) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    Moments x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        Moments y{__shfl_up(x.x, o), __shfl_up(x.y, o), __shfl_up(x.z, o), __shfl_up(x.m, o)};
-        if ((int)lane >= o) x = x + y;
-    }
+    const Moments x{wave_scan_f64(v.x), wave_scan_f64(v.y), wave_scan_f64(v.z), wave_scan_f64(v.m)};
     if (lane == 63) s_wave[wave] = x;
     __syncthreads();
     Moments off{0, 0, 0, 0};
@@ -906,9 +946,12 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
             atomicAdd(&s_hist[1 + (left > right ? left : right) + 1], 1u);  // its leaf
             if (k + 1 < n && me_next == me) collide += 1u;
         }
+        msum = msum + item;  // (per thread over its rounds; the workgroup's total once, below)
+    }
+    {   // the tile's moments: the threads' sums added in a fixed order (wave scan, then the waves in order)
         Moments total;
-        (void)block_scan_moments(item, s_wave, &total);  // fixed order inside the round
-        msum = msum + total;
+        (void)block_scan_moments(msum, s_wave, &total);
+        msum = total;
     }
     if (nint_sum) atomicAdd(&s_hist[0], nint_sum);
     if (collide) atomicAdd(&status[2], collide);
@@ -942,11 +985,7 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
             if (i4 * 4u + 2u >= ntiles) v.z = 0u;
             if (i4 * 4u + 3u >= ntiles) v.w = 0u;
             const uint32_t sum = v.x + v.y + v.z + v.w;
-            uint32_t x = sum;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = __shfl_up(x, o);
-                if ((int)lane >= o) x += y;
-            }
+            const uint32_t x = wave_scan_u32(sum);
             if (lane == 63u) s_w[wave] = x;
             __syncthreads();
             uint32_t before = 0u, chunk_total = 0u;
@@ -973,11 +1012,7 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
         const uint32_t t_lo = min(threadIdx.x * per, ntiles), t_hi = min(t_lo + per, ntiles);
         double sum = 0.0;
         for (uint32_t i = t_lo; i < t_hi; ++i) sum += vals[4u * (size_t)i];
-        double x = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const double y = __shfl_up(x, o);
-            if ((int)lane >= o) x += y;
-        }
+        const double x = wave_scan_f64(sum);
         if (lane == 63u) s_wtot[wave] = x;
         __syncthreads();
         double run = 0.0;
@@ -1041,12 +1076,8 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
         // are not kept but counted again when the ids are written (23 live registers and two unrolled 23-step loops
         // otherwise: 95 VGPRs, 3,800 instructions).
         int d_lo = valid ? (right > left ? left + 1 : leafd) : kMaxDepth + 1, d_hi = valid ? leafd : -1;
-        for (int o = 32; o > 0; o >>= 1) {
-            d_lo = min(d_lo, __shfl_xor(d_lo, o));
-            d_hi = max(d_hi, __shfl_xor(d_hi, o));
-        }
-        d_lo = __builtin_amdgcn_readfirstlane(d_lo);
-        d_hi = __builtin_amdgcn_readfirstlane(d_hi);
+        d_lo = __builtin_amdgcn_readlane(wave_min_to_lane63(d_lo), 63);
+        d_hi = __builtin_amdgcn_readlane(wave_max_to_lane63(d_hi), 63);
         if (lane <= (uint32_t)kMaxDepth) s_cnt[wave][lane] = 0u;
         __builtin_amdgcn_wave_barrier();
         for (int d = d_lo; d <= d_hi; ++d) {
@@ -1054,8 +1085,6 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
             if (lane == 0) s_cnt[wave][d] = (uint32_t)__popcll(bal);
         }
         const uint32_t ni = valid && right > left ? (uint32_t)(right - left) : 0u;
-        uint32_t ni_total;
-        const uint32_t slot0 = slot_run + block_exclusive_scan_256(ni, s_scan, &ni_total);  // (syncs)
         Moments item{0, 0, 0, 0};
         if (valid) {
             const float4 p = posm[k];
@@ -1067,8 +1096,31 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
                 acc_out[k] = acc_in[src];
             }
         }
-        Moments mom_total;
-        const Moments mom0 = mom_run + block_scan_moments(item, s_wave, &mom_total);  // (syncs)
+        // the opened-cell count and the four moments scanned over the workgroup together: the waves' totals of
+        // both meet in LDS behind ONE pair of barriers (two scans, two pairs, before)
+        uint32_t ni_total, slot0;
+        Moments mom_total, mom0;
+        {
+            const uint32_t xi = wave_scan_u32(ni);
+            const Moments xm{wave_scan_f64(item.x), wave_scan_f64(item.y), wave_scan_f64(item.z), wave_scan_f64(item.m)};
+            if (lane == 63u) {
+                s_scan[wave] = xi;
+                s_wave[wave] = xm;
+            }
+            __syncthreads();
+            uint32_t offi = 0u;
+            Moments offm{0, 0, 0, 0};
+            for (uint32_t w = 0; w < wave; ++w) {
+                offi += s_scan[w];
+                offm = offm + s_wave[w];
+            }
+            ni_total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+            mom_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            __syncthreads();
+            slot0 = slot_run + offi + xi - ni;
+            mom0 = mom_run + Moments{offm.x + xm.x - item.x, offm.y + xm.y - item.y, offm.z + xm.z - item.z,
+                                     offm.m + xm.m - item.m};
+        }
         if (k <= n) prefix[k] = mom0;  // includes prefix[n] = the grand total
         if (valid) int_slot[k] = slot0;
         for (int d = d_lo; d <= d_hi; ++d) {
@@ -1535,20 +1587,6 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
 constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
 constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (7 KiB); see the batch-size rule in the loop
 constexpr uint32_t kCellReserve = 160;
-
-#define NB_DPP(old, src, ctrl, row_mask) \
-    ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (row_mask), 0xf, false))
-
-// inclusive prefix sum over the 64 lanes (row_shr within the 16-lane rows, then the row totals)
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x) {
-    x += NB_DPP(0, x, 0x111, 0xf);  // row_shr:1
-    x += NB_DPP(0, x, 0x112, 0xf);  // row_shr:2
-    x += NB_DPP(0, x, 0x114, 0xf);  // row_shr:4
-    x += NB_DPP(0, x, 0x118, 0xf);  // row_shr:8
-    x += NB_DPP(0, x, 0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
-    x += NB_DPP(0, x, 0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
-    return x;
-}
 
 // sum over the 64 lanes, in a fixed order; the total lands in lane 63
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
