@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
     uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
     Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds, const uint32_t *__restrict__ order,
     const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in, float4 *__restrict__ vel_out,
-    float4 *__restrict__ acc_out) {
+    float4 *__restrict__ acc_out, NodeRec *__restrict__ rec) {
     __shared__ uint32_t s_cnt[4][kMaxDepth + 1], s_run[kMaxDepth + 1], s_scan[4];
     __shared__ Moments s_wave[4];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1086,8 +1086,9 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
         }
         const uint32_t ni = valid && right > left ? (uint32_t)(right - left) : 0u;
         Moments item{0, 0, 0, 0};
+        float4 p{0.f, 0.f, 0.f, 0.f};
         if (valid) {
-            const float4 p = posm[k];
+            p = posm[k];
             const double m = (double)p.w;
             item = Moments{(double)p.x * m, (double)p.y * m, (double)p.z * m, m};
             if (vel_in) {  // the rest of sort_particles (tree.rs:564-602): velocities and accelerations
@@ -1132,6 +1133,9 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
                 const uint32_t id = before + (uint32_t)__popcll(bal & lt_mask);
                 if (d == leafd) {
                     leaf_id[k] = id;
+                    // the walk's record of the leaf (tree.rs:521-534: cog = position, mass): written here, where
+                    // the body is in registers, so that fill_kernel runs over the internal cells only
+                    if (id < cap) rec[id] = NodeRec{p, 0u, 0u, k, -1.0f};
                 } else {
                     // (a clustered input can open far more internal cells than the 4N capacity)
                     const uint32_t slot = slot0 + (uint32_t)(d - left - 1);
@@ -1173,6 +1177,9 @@ constexpr uint32_t kFillEagerMax = 262144;  // bodies up to which fill_kernel fe
 constexpr uint32_t kFillEagerAgainFrom = 2097152;
 
 // EAGER_MOM: also the first moment prefix ahead of the search (small problems only: see below)
+// !AOS: a thread per INTERNAL cell, found through its slot (int_id[slot], slots counted by cells_a/cells_c: row 0 of
+// the tile table): two thirds of the nodes are leaves, whose records cells_c_kernel has already written, and a
+// wave of 64 internal cells does not wait for the long chain of a few of them while most of its lanes idle.
 template <bool AOS, bool EAGER, bool EAGER_MOM = EAGER>
 __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint32_t n_cap,
                             const uint32_t *__restrict__ n_nodes_p,
@@ -1184,12 +1191,16 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const Moments *__restrict__ mom, const uint32_t *__restrict__ depth_base,
                             const uint32_t *__restrict__ bound_bits,
                             float4 *__restrict__ cogm, uint32_t *__restrict__ bodies,
-                            uint32_t *__restrict__ child, NodeRec *__restrict__ rec, float inv_theta2) {
-    // (the grid covers ~1.75 N nodes -- a uniform octree has ~1.5 N, the capacity is 4 N and the count is only
-    // known on the device: the workgroups that would find nothing to do are not launched, a deeper tree
-    // takes the loop)
+                            uint32_t *__restrict__ child, NodeRec *__restrict__ rec, float inv_theta2,
+                            const uint32_t *__restrict__ n_internal_p) {
+    // (the grid covers ~1.75 N nodes / ~0.75 N internal cells -- a uniform octree has ~1.5 N / 0.5 N, the
+    // capacity is 4 N and the counts are only known on the device: the workgroups that would find nothing to do
+    // are not launched, a deeper tree takes the loop)
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n_nodes; id += gridDim.x * blockDim.x) {
+    const uint32_t n_work = AOS ? n_nodes : min(*n_internal_p, n_cap);
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_work; t += gridDim.x * blockDim.x) {
+        const uint32_t id = AOS ? t : int_id[t];
+        if (id >= n_nodes) continue;
         const uint32_t k = node_first[id];
         const uint32_t dd = node_depth[id];
         uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3093,22 +3104,22 @@ class TreeSim final : public SimBase {
                            row_total, bound_slots);
         hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
                            depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
-                           rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d]);
+                           rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d], rec);
         va_gathered = with_va;
         // 6: node contents
-        const uint32_t gnodes = (std::min<uint64_t>(node_cap, (uint64_t)n + 3ull * (n / 4u) + 256ull) + 255) / 256;
+        const uint32_t gnodes = (std::min<uint64_t>(node_cap, 3ull * (n / 4u) + 256ull) + 255) / 256;  // internal cells
         if (n <= kFillEagerMax)
             hipLaunchKernelGGL((fill_kernel<false, true>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2(), scalars + 40);
         else if (n >= kFillEagerAgainFrom)
             hipLaunchKernelGGL((fill_kernel<false, true, false>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2(), scalars + 40);
         else
             hipLaunchKernelGGL((fill_kernel<false, false>), dim3(gnodes), b256, 0, stream, skeys, n, node_cap, n_nodes,
                                node_first, node_depth, cpl, int_slot, leaf_id, int_id, order, posm[d],
-                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2());
+                               mom_prefix, depth_base, bound_bits, cogm, bodies, child, rec, inv_theta2(), scalars + 40);
         NB_HIP_TRY(hipGetLastError());
         return NB_OK;
     }
@@ -3302,7 +3313,7 @@ class TreeSim final : public SimBase {
             hipLaunchKernelGGL((fill_kernel<true, false>), dim3((node_cap + 255) / 256), dim3(256), 0, stream, sorted_keys,
                                n, node_cap, scalars + 1, node_first, node_depth, cpl, int_slot, leaf_id, int_id,
                                order, posm[cur ^ 1], mom_prefix, scalars + 16, scalars + 0, cogm, bodies, child,
-                               rec, inv_theta2());
+                               rec, inv_theta2(), scalars + 40);
             hipLaunchKernelGGL(tree_to_aos_kernel, dim3((nodes + 255) / 256), dim3(256), 0, stream, cogm,
                                bodies, child, nodes, d_tree_aos);
             NB_HIP_TRY(hipMemcpyAsync(dst, d_tree_aos, sizeof(nb_octant) * m, hipMemcpyDeviceToHost, stream));
