@@ -690,23 +690,38 @@ __global__ __launch_bounds__(256) void runs_fix_kernel(uint64_t *keys, uint32_t 
 // copy of the index array costs plus a few gathers.  Runs of 64 or more (clustered input) are left to the
 // workgroup that holds their first body, as in runs_fix_kernel: ranked by counting up to kRunCountMax, radix-
 // sorted beyond, and copied to vals_out.  stat / probe: as runs_fix_kernel.
+constexpr uint32_t kRankItems = 1;  // positions per thread (4: -10 us at 4,000,000 bodies, +8 us at 131,072 where most bodies sit in runs)
 __global__ __launch_bounds__(256) void runs_rank_kernel(const uint32_t *__restrict__ khi, const uint64_t *__restrict__ keys,
                                                         uint32_t *vals_in, uint32_t *vals_out, uint64_t *run_keys,
                                                         uint64_t *alt_keys, uint32_t n, uint32_t low_bits,
                                                         uint32_t probe_bits, uint32_t *__restrict__ stat,
                                                         uint32_t *__restrict__ stat_clear) {
-    __shared__ uint32_t s_long[256 / kRunWave + 1], s_n[2];
+    __shared__ uint32_t s_long[kRankItems * 256 / kRunWave + 1], s_n[2];
     __shared__ uint32_t s_hist[256], s_wcnt[4][256], s_w[4], s_flag;
     const uint32_t hs = low_bits - 32u;
     if (threadIdx.x < 2u) s_n[threadIdx.x] = 0u;
     if (blockIdx.x == 0u && threadIdx.x == 0u) stat_clear[0] = stat_clear[2] = stat_clear[4] = 0u;
     __syncthreads();
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < n) {
-        const uint32_t hw = khi[k], hi = hw >> hs;
-        const bool left = k > 0u && (khi[k - 1u] >> hs) == hi, right = k + 1u < n && (khi[k + 1u] >> hs) == hi;
+    // kRankItems rounds of 256 consecutive positions per workgroup; what every position needs first -- its high
+    // word, its neighbours', its index -- is fetched for all rounds together (independent loads in flight
+    // together: the kernel is a chain of short dependent loads otherwise)
+    uint32_t hw_[kRankItems], hl_[kRankItems], hr_[kRankItems], val_[kRankItems];
+#pragma unroll
+    for (uint32_t c = 0; c < kRankItems; ++c) {
+        const uint32_t k = (blockIdx.x * kRankItems + c) * 256u + threadIdx.x;
+        hw_[c] = k < n ? khi[k] : 0u;
+        hl_[c] = k > 0u && k < n ? khi[k - 1u] : 0u;
+        hr_[c] = k + 1u < n ? khi[k + 1u] : 0u;
+        val_[c] = k < n ? vals_in[k] : 0u;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < kRankItems; ++c) {
+        const uint32_t k = (blockIdx.x * kRankItems + c) * 256u + threadIdx.x;
+        if (k >= n) continue;
+        const uint32_t hw = hw_[c], hi = hw >> hs;
+        const bool left = k > 0u && (hl_[c] >> hs) == hi, right = k + 1u < n && (hr_[c] >> hs) == hi;
         if (!left && !right) {
-            vals_out[k] = vals_in[k];
+            vals_out[k] = val_[c];
         } else {
             uint32_t s = k, e = k + 1u;  // the run [s, e), as far as it matters: up to kRunWave places either way
             while (s > 0u && k - s < kRunWave && (khi[s - 1u] >> hs) == hi) --s;
@@ -714,7 +729,7 @@ __global__ __launch_bounds__(256) void runs_rank_kernel(const uint32_t *__restri
             if (e - s >= kRunWave) {  // a long run: its first body's workgroup sorts it
                 if (!left) s_long[atomicAdd(&s_n[0], 1u)] = k;
             } else {
-                const uint32_t mine = vals_in[k];
+                const uint32_t mine = val_[c];
                 const uint64_t ki = keys[mine];
                 uint32_t rank = 0u;
                 for (uint32_t j = s; j < e; ++j) {
@@ -1596,7 +1611,11 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
 #define NB_WALK_MIN_WAVES 5  // waves per SIMD the register budget of the cells walk is held to
 #endif
 constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
-constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave (7 KiB); see the batch-size rule in the loop
+constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word form (7 KiB); see the batch-size rule in the loop
+#ifndef NB_CELL_STACK_PACKED
+#define NB_CELL_STACK_PACKED 1024  // (4 KiB x 32 waves per CU; 896: +1.7 % at 2^20 bodies theta 0.5, larger: no further gain)
+#endif
+constexpr uint32_t kCellStackPacked = NB_CELL_STACK_PACKED;  // ... one-word form
 constexpr uint32_t kCellReserve = 160;
 
 // sum over the 64 lanes, in a fixed order; the total lands in lane 63
@@ -1712,7 +1731,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     using Ent = typename Stack::Ent;
     static_assert(!PACKED || G <= 8, "a packed entry has 8 mask bits");
     // (the stack's LDS also carries the G x 64 floats of the final reduction)
-    constexpr uint32_t kEntries = kCellStack * sizeof(Ent) >= (uint32_t)G * 256u ? kCellStack : (uint32_t)G * 256u / sizeof(Ent);
+    constexpr uint32_t kStack = PACKED ? kCellStackPacked : kCellStack;
+    constexpr uint32_t kEntries = kStack * sizeof(Ent) >= (uint32_t)G * 256u ? kStack : (uint32_t)G * 256u / sizeof(Ent);
     __shared__ Ent s_stack[kCellBlockWaves][kEntries];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -1790,7 +1810,7 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             // level below the cell it started from: 7 x 21 = 147 < kCellReserve slots, and a batch of
             // several cells is only taken while it leaves the reserve untouched -- the stack cannot
             // overflow on a consistent tree (the check below guards against a corrupt one).
-            const uint32_t free_slots = kCellStack - sp;
+            const uint32_t free_slots = kStack - sp;
             if (free_slots < 7u) {
                 overflowed = true;
                 break;
@@ -3030,7 +3050,7 @@ class TreeSim final : public SimBase {
                 // (scratch for a long run's keys: the moment prefixes, which cells_c_kernel writes later)
                 uint64_t *scratch = reinterpret_cast<uint64_t *>(mom_prefix);
                 const uint32_t par = build_seq & 1u;
-                hipLaunchKernelGGL(runs_rank_kernel, dim3((n + 255u) / 256u), b256, 0, stream, khi[kb], keys[0], idx[kb],
+                hipLaunchKernelGGL(runs_rank_kernel, dim3((n + 256u * kRankItems - 1u) / (256u * kRankItems)), b256, 0, stream, khi[kb], keys[0], idx[kb],
                                    idx[kb ^ 1], scratch, scratch + n, n, 32u + hs0,
                                    sort_boost ? std::min(62u, 32u + hs0 + kSortBits) : 0u, scalars + 8 + par,
                                    scalars + 8 + (par ^ 1u));
