@@ -1599,7 +1599,7 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
     return o;
 }
 #ifndef NB_CELL_STACK
-#define NB_CELL_STACK 896
+#define NB_CELL_STACK 1024
 #endif
 #ifndef NB_WALK_WAVES
 #define NB_WALK_WAVES 1
@@ -1611,7 +1611,7 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
 #define NB_WALK_MIN_WAVES 5  // waves per SIMD the register budget of the cells walk is held to
 #endif
 constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
-constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word form (7 KiB); see the batch-size rule in the loop
+constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word form (8 KiB); see the batch-size rule in the loop
 #ifndef NB_CELL_STACK_PACKED
 #define NB_CELL_STACK_PACKED 1024  // (4 KiB x 32 waves per CU; 896: +1.7 % at 2^20 bodies theta 0.5, larger: no further gain)
 #endif
