@@ -856,6 +856,9 @@ __device__ __forceinline__ bool starts_node_at(int left, int right, int d) {
     return internal || leaf;
 }
 
+// the record of an internal cell's slot (cells_c_kernel -> fill_kernel): the node id below its depth
+constexpr uint32_t kSlotDepthShift = 27, kSlotIdMask = (1u << kSlotDepthShift) - 1u;
+
 // What the walk reads per cell, in one 32-byte scalar load: centre of gravity + mass, and the
 // link {first child id, child count} (leaf: {sorted position of its body, 0}).
 struct __attribute__((aligned(32))) NodeRec {
@@ -957,6 +960,8 @@ __global__ __launch_bounds__(256) void cells_a_kernel(
             if (k == 0) cpl[0] = -1;
             cpl[k + 1] = (int8_t)right;
             nint_sum += right > left ? (uint32_t)(right - left) : 0u;  // internal cells this body opens
+            // (LDS atomics, 256 of a round on two or three words: a loop over the wave's depths with ballots, one add
+            // per wave and depth, measured SLOWER -- 15.9 -> 19.3 us at 2^20 bodies)
             for (int d = left + 1; d <= right; ++d) atomicAdd(&s_hist[1 + d], 1u);
             atomicAdd(&s_hist[1 + (left > right ? left : right) + 1], 1u);  // its leaf
             if (k + 1 < n && me_next == me) collide += 1u;
@@ -1048,7 +1053,7 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
     const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ row_total,
     uint32_t *__restrict__ depth_base, uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ status,
     const float4 *__restrict__ posm, uint32_t *__restrict__ int_slot, uint32_t *__restrict__ leaf_id,
-    uint32_t *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
+    uint2 *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
     Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds, const uint32_t *__restrict__ order,
     const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in, float4 *__restrict__ vel_out,
     float4 *__restrict__ acc_out, NodeRec *__restrict__ rec) {
@@ -1154,7 +1159,9 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
                 } else {
                     // (a clustered input can open far more internal cells than the 4N capacity)
                     const uint32_t slot = slot0 + (uint32_t)(d - left - 1);
-                    if (slot < cap) int_id[slot] = id;
+                    // the slot's record: what fill_kernel needs to start on the cell without looking anything up --
+                    // {first body | 'body k opens the next depth too' << 31, id | depth << 27}
+                    if (slot < cap) int_id[slot] = uint2{k | (d + 1 <= right ? 0x80000000u : 0u), id | ((uint32_t)d << kSlotDepthShift)};
                 }
                 if (id < cap) {
                     node_first[id] = k;
@@ -1201,7 +1208,7 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
                             const uint32_t *__restrict__ node_first,
                             const uint8_t *__restrict__ node_depth, const int8_t *__restrict__ cpl,
                             const uint32_t *__restrict__ int_slot,
-                            const uint32_t *__restrict__ leaf_id, const uint32_t *__restrict__ int_id,
+                            const uint32_t *__restrict__ leaf_id, const uint2 *__restrict__ int_id,
                             const uint32_t *__restrict__ order, const float4 *__restrict__ posm,
                             const Moments *__restrict__ mom, const uint32_t *__restrict__ depth_base,
                             const uint32_t *__restrict__ bound_bits,
@@ -1214,10 +1221,14 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
     const uint32_t n_nodes = min(*n_nodes_p, n_cap);
     const uint32_t n_work = AOS ? n_nodes : min(*n_internal_p, n_cap);
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_work; t += gridDim.x * blockDim.x) {
-        const uint32_t id = AOS ? t : int_id[t];
+        // !AOS: everything the cell starts from comes in its slot record (written by cells_c_kernel): two dependent
+        // look-ups (id -> first body, depth) and the two prefix lengths of the body fewer per cell
+        uint2 si{0u, 0u};
+        if (!AOS) si = int_id[t];
+        const uint32_t id = AOS ? t : si.y & kSlotIdMask;
         if (id >= n_nodes) continue;
-        const uint32_t k = node_first[id];
-        const uint32_t dd = node_depth[id];
+        const uint32_t k = AOS ? node_first[id] : si.x & 0x7fffffffu;
+        const uint32_t dd = AOS ? node_depth[id] : si.y >> kSlotDepthShift;
         uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
             const float4 p = posm[k];
@@ -1236,10 +1247,16 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             // bodies.  At 2^20 bodies the kernel is bound by HBM traffic and the speculative loads cost
             // 6 us: not EAGER there.)
             const uint64_t key_k = keys[k];
-            const int left = cpl[k], right = cpl[k + 1];
+            int left = 0, right = 0;
+            if (AOS) {
+                left = cpl[k];
+                right = cpl[k + 1];
+            }
+            // body k also opens the cell one level down: its slot is the next one (a body's cells have consecutive slots)
+            const bool opens_next = AOS ? (int)d + 1 <= right : (si.x >> 31) != 0u;
             // (only one of the two is needed: both are fetched ahead only where latency, not traffic, binds)
-            const bool opens_next = (int)d + 1 <= right;  // body k also opens the cell one level down
-            const uint32_t slot_k = (EAGER || opens_next) ? int_slot[k] : 0u;
+            const uint32_t slot_k = AOS && opens_next ? int_slot[k] : 0u;
+            const uint32_t next_id = !AOS && (EAGER || opens_next) && t + 1u < n_cap ? int_id[t + 1u].y & kSlotIdMask : ~0u;
             const uint32_t leaf_k = (EAGER || !opens_next) ? leaf_id[k] : 0u;
             Moments a{0, 0, 0, 0};
             if (EAGER_MOM) a = mom[k];  // (large problems: beside mom[end] below -- mostly the same cache line, and
@@ -1273,9 +1290,11 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
             // children: the depth-(d+1) nodes whose first body lies in [k, end) -- consecutive ids
             // (nodes of one depth are numbered in key order), starting with body k's own child
             uint32_t f;
-            if (opens_next) {
+            if (opens_next && AOS) {
                 const uint32_t slot = slot_k + (d - (uint32_t)(left + 1) + 1u);
-                f = slot < n_cap ? int_id[slot] : ~0u;
+                f = slot < n_cap ? int_id[slot].y & kSlotIdMask : ~0u;
+            } else if (opens_next) {
+                f = next_id;
             } else {
                 f = leaf_k;
             }
@@ -1599,7 +1618,7 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
     return o;
 }
 #ifndef NB_CELL_STACK
-#define NB_CELL_STACK 1024
+#define NB_CELL_STACK 896
 #endif
 #ifndef NB_WALK_WAVES
 #define NB_WALK_WAVES 1
@@ -1611,7 +1630,7 @@ __device__ __forceinline__ uint32_t shl1_carry_in(uint32_t v, uint64_t bit) {
 #define NB_WALK_MIN_WAVES 5  // waves per SIMD the register budget of the cells walk is held to
 #endif
 constexpr uint32_t kCellBlockWaves = NB_WALK_BLOCK_WAVES;  // waves (= groups) per workgroup
-constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word form (8 KiB); see the batch-size rule in the loop
+constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word form (7 KiB: 22 waves per CU; 1,024 entries = 8 KiB = 20 waves: +5 % at 16 M bodies); see the batch-size rule in the loop
 #ifndef NB_CELL_STACK_PACKED
 #define NB_CELL_STACK_PACKED 1024  // (4 KiB x 32 waves per CU; 896: +1.7 % at 2^20 bodies theta 0.5, larger: no further gain)
 #endif
@@ -2513,7 +2532,7 @@ class TreeSim final : public SimBase {
         theta = add.theta > 0.f ? add.theta : NB_DEFAULT_THETA;
         n_capacity = n;
         const size_t nn = n ? n : 1;
-        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, 0xfffffff0u);  // 4N as tree.rs:188-190
+        node_cap = (uint32_t)std::min<size_t>(4 * nn + 8, kSlotIdMask);  // 4N as tree.rs:188-190 (node ids take 27 bits of a slot record: 33 million bodies before the cap is less than 4N)
         sort_items = nn <= kSortSmallMax ? kSortItemsSmall : kSortItems;
         sort_blocks = (uint32_t)((nn + kSortThreads * sort_items - 1) / (kSortThreads * sort_items));
         cell_tiles = (uint32_t)std::max({std::min<size_t>(nn, 131072) / 256, std::min<size_t>(nn, 524288) / 512, nn / kCellTile}) + 4;  // capacity
@@ -2536,7 +2555,7 @@ class TreeSim final : public SimBase {
         if (int rc = alloc(&tile_u32, sizeof(uint32_t) * kCellRows * ((size_t)cell_tiles + 4))) return rc;
         if (int rc = alloc(&tile_mom, sizeof(Moments) * (size_t)cell_tiles)) return rc;
         if (int rc = alloc(&leaf_id, sizeof(uint32_t) * nn)) return rc;
-        if (int rc = alloc(&int_id, sizeof(uint32_t) * (size_t)node_cap)) return rc;
+        if (int rc = alloc(&int_id, sizeof(uint2) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_first, sizeof(uint32_t) * (size_t)node_cap)) return rc;
         if (int rc = alloc(&node_depth, (size_t)node_cap)) return rc;
         if (int rc = alloc(&rec, sizeof(NodeRec) * (size_t)node_cap)) return rc;
@@ -3639,7 +3658,8 @@ class TreeSim final : public SimBase {
     nb_particle *d_aos = nullptr;
     nb_octant *d_tree_aos = nullptr;
     uint32_t *hist = nullptr, *totals = nullptr, *int_slot = nullptr;
-    uint32_t *leaf_id = nullptr, *int_id = nullptr;
+    uint32_t *leaf_id = nullptr;
+    uint2 *int_id = nullptr;  // per internal-cell slot: {first body | opens-next flag, id | depth << 27}
     uint32_t *node_first = nullptr, *bodies = nullptr, *child = nullptr, *scalars = nullptr;
     uint8_t *node_depth = nullptr;
     int8_t *cpl = nullptr;
