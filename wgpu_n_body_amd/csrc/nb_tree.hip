@@ -188,6 +188,10 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
     const float bound = fmaxf(1.0f, __uint_as_float(bmax));  // never below 1.0, tree.rs:427-433
     if (blockIdx.x == 0 && threadIdx.x == 0 && bound_src != bound_bits) *bound_bits = __float_as_uint(bound);
     const float root_w = bound * 2.0f;  // root width, tree.rs:465
+    // The quarter widths of the 21 levels, width / 4 (shift_node_center) with width halved per level: exact powers
+    // of two times root_w, i.e. root_w's bit pattern with its exponent lowered -- wave-uniform integers the scalar
+    // unit computes, where `w / 4.0f; w = w / 2.0f` cost two vector multiplies per level and body.
+    const uint32_t root_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(root_w));
     // (the loads of a tile's bodies first, all in flight together: one body after the other the
     // kernel waited out eight memory latencies per thread)
     float4 pv[kSortItems];
@@ -201,18 +205,17 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
         const uint32_t i = (blockIdx.x * items + c) * blockDim.x + threadIdx.x;
         if (c >= items || i >= n) break;
         const float4 p = pv[c];
-        float cx = 0.f, cy = 0.f, cz = 0.f, w = root_w;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
         uint64_t key = 0;
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) {
 #pragma clang fp contract(off)
             const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
             key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
-            const float q = w / 4.0f;  // shift_node_center
-            cx = cx + (bx ? q : -q);
+            const float q = __uint_as_float(root_bits - ((uint32_t)(l + 2) << 23));  // (root_w / 2^l) / 4, exactly
+            cx = cx + (bx ? q : -q);  // shift_node_center
             cy = cy + (by ? q : -q);
             cz = cz + (bz ? q : -q);
-            w = w / 2.0f;
         }
         keys[i] = key;
         if (key_hi) key_hi[i] = (uint32_t)(key >> 32);
