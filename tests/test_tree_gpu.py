@@ -470,7 +470,7 @@ def test_tree_step_in_two_phases(gpu):
 @pytest.mark.parametrize("n,init", [(20000, "uniform"), (20000, "disc"), (100000, "uniform"), (100000, "disc"),
                                     (600000, "uniform"), (600000, "disc")])
 def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
-    """Above 16,384 bodies the radix sort covers only the high key bits (3 passes of 8 bits at 20,000
+    """Above 12,288 bodies the radix sort covers only the high key bits (3 passes of 8 bits at 20,000
     and 100,000 bodies, 4 at 600,000 -- 3 of 9 bits with `tree_sort_wide` 1) and fixes the runs
     that tie there up afterwards; `tree_sort_mode` 0 runs seven 9-bit passes over the whole key instead.  Both must give the same stable
     order by key (which the oracle pins at <= 20,000 bodies above and at 2^20 / 4 M / 8 M bodies in
@@ -488,6 +488,29 @@ def test_high_digit_sort_with_fix_up_gives_the_stable_key_order(gpu, n, init):
     assert np.array_equal(np.sort(a["order"]), np.arange(n, dtype=np.uint32))
     assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
     assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,init", [(1, "uniform"), (255, "uniform"), (256, "disc"), (3000, "spherical"),
+                                    (12288, "uniform"), (13000, "disc"), (16127, "uniform"), (16128, "uniform"),
+                                    (40000, "disc"), (65279, "uniform")])
+def test_tile_scan_inside_cells_c_gives_the_launched_scan_bits(gpu, n, init):
+    """Up to 64 tiles of 256 bodies (16,127 bodies + the closing prefix) cells_c_kernel sums the tile table
+    itself instead of reading cells_scan_kernel's scan (one dependent launch fewer); `tree_cell_scan_inline` 0
+    launches the scan at every size, 2 uses the in-kernel form up to the 256 tiles it can do.  Node ids, slots
+    and the binary64 moment prefixes must come out the same: order, tree and state bit for bit, over 3 steps
+    (both sort paths: counted up to 12,288 bodies, radix + fix-up above)."""
+    nb = gpu
+    sp = nb.SimParams(particle_num=n)
+    state = nb.as_floats(getattr(nb.inits, init + "_init")(sp, seed=7 + n % 89))
+    runs = [run_tree(nb, state, 0.75, steps=3, count=False, tuning={"tree_cell_scan_inline": v}) for v in (0, 1, 2)]
+    a = runs[0]
+    assert not a["status"].any()
+    for b in runs[1:]:
+        assert not b["status"].any()
+        assert np.array_equal(a["order"], b["order"])
+        assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
+        assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
 
 
 def test_visualize_workload_at_its_own_size_against_oracle(gpu, oracle):

@@ -17,7 +17,7 @@
 //                         over the HIGH digits only -- 2 or 3 passes on (high word of the key, index)
 //                         pairs, 3e -- then a fix-up of the bodies that tie there (runs_rank_kernel:
 //                         a thread per body; runs_fix_kernel for the 64-bit form, 3d); the whole sort
-//                         in one launch by counting up to 16,384 bodies (3c); 8 passes over the
+//                         in one launch by counting up to 12,288 bodies (3c); 8 passes over the
 //                         whole key as the cross-check (tuning key tree_sort_mode 0)
 //   4-6a cells_a/scan/c   bodies into sorted order = the reference's DFS order (tree.rs:564-602);
 //                         a cell at depth d exists for every key-prefix run: body k opens the
@@ -432,7 +432,9 @@ __global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
 // them.  A workgroup owns 64 bodies; its 16 waves split the j range, each staging its slice in LDS;
 // (key_j, j) < (key_i, i) is evaluated as key_j < key_i + [j < i], one compare per pair once a
 // wave's j slice lies entirely below or above its bodies.
-constexpr uint32_t kRankSortMax = 16384;
+// (measured per runner.step(), theta 0.75: 8,192 bodies 77.0 us counted / 80.6 radix; 12,288: 84.8 / 84.9;
+// 16,384: 93.7 / 89.1 -- the two-pass high-word radix sort with its thread-per-body fix-up takes over there)
+constexpr uint32_t kRankSortMax = 12288;
 constexpr uint32_t kRankWaves = 16;
 constexpr int kRankUnroll = 32;
 
@@ -1051,24 +1053,72 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
 
 // C: node ids (rank of (body k, depth d) among the nodes of depth d in key order = the reference's
 // BFS allocation order), slots of the opened cells, moment prefixes
+// SCAN_INLINE (up to kCellInlineTiles tiles: the sizes at which a step is a chain of launch latencies): B inside C.
+// The tile table comes as cells_a_kernel wrote it and every workgroup sums the tiles before its own itself --
+// the u32 rows by a lane per row and eighth of the tiles, the moments by a thread per tile in
+// cells_scan_kernel's own order of additions (wave scan, then the waves in order: the same bits) -- one
+// dependent launch fewer per step.  Per runner.step(), theta 0.75, B inside C / B launched: 1,024 bodies
+// 51.1 / 54.1 us, 4,096: 60.3 / 65.7, 8,192: 70.5 / 75.7, 12,288: 79.5 / 83.0; 16,384 (65 tiles): 84.8 / 85.2,
+// 32,768: 98.0 / 98.8, 65,279 (255 tiles): 123.8 / 122.5 -- the code handles up to 256 tiles, the host uses it to 64.
+constexpr uint32_t kCellInlineTiles = 64;
+template <bool SCAN_INLINE>
 __global__ __launch_bounds__(256) void cells_c_kernel(
     const int8_t *__restrict__ cpl, uint32_t n, const uint32_t *__restrict__ tile_u32,
-    const Moments *__restrict__ tile_mom, uint32_t stride, const uint32_t *__restrict__ row_total,
+    const Moments *__restrict__ tile_mom, uint32_t stride, uint32_t *__restrict__ row_total,
     uint32_t *__restrict__ depth_base, uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ status,
     const float4 *__restrict__ posm, uint32_t *__restrict__ int_slot, uint32_t *__restrict__ leaf_id,
     uint2 *__restrict__ int_id, uint32_t *__restrict__ node_first, uint8_t *__restrict__ node_depth,
     Moments *__restrict__ prefix, uint32_t cap, uint32_t rounds, const uint32_t *__restrict__ order,
     const float4 *__restrict__ vel_in, const float4 *__restrict__ acc_in, float4 *__restrict__ vel_out,
-    float4 *__restrict__ acc_out, NodeRec *__restrict__ rec) {
+    float4 *__restrict__ acc_out, NodeRec *__restrict__ rec, uint32_t *__restrict__ bound_slots) {
     __shared__ uint32_t s_cnt[4][kMaxDepth + 1], s_run[kMaxDepth + 1], s_scan[4];
     __shared__ Moments s_wave[4];
+    __shared__ uint32_t s_before[8][kCellRows], s_all[8][kCellRows];
+    auto sum8 = [](const uint32_t (*a)[kCellRows], uint32_t r) {
+        return a[0][r] + a[1][r] + a[2][r] + a[3][r] + a[4][r] + a[5][r] + a[6][r] + a[7][r];
+    };
+    __shared__ Moments s_mom_run;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    if (SCAN_INLINE) {
+        const uint32_t ntiles = gridDim.x;
+        if ((lane & 31u) < kCellRows) {  // row `lane & 31`, this half-wave's eighth of the tiles
+            const uint32_t r = lane & 31u, part = wave * 2u + (lane >> 5);
+            const uint32_t q = (ntiles + 7u) / 8u, t_lo = min(part * q, ntiles), t_hi = min(t_lo + q, ntiles);
+            const uint32_t *row = tile_u32 + (size_t)r * stride;
+            uint32_t before = 0u, all = 0u;
+#pragma unroll 4
+            for (uint32_t t = t_lo; t < t_hi; ++t) {
+                const uint32_t v = row[t];
+                all += v;
+                before += t < blockIdx.x ? v : 0u;
+            }
+            s_before[part][r] = before;
+            s_all[part][r] = all;
+        }
+        Moments v{0, 0, 0, 0};
+        if (threadIdx.x < ntiles) v = tile_mom[threadIdx.x];
+        const Moments x{wave_scan_f64(v.x), wave_scan_f64(v.y), wave_scan_f64(v.z), wave_scan_f64(v.m)};
+        if (lane == 63u) s_wave[wave] = x;
+        __syncthreads();
+        if (threadIdx.x == blockIdx.x) {
+            Moments run{0, 0, 0, 0};
+            for (uint32_t w = 0; w < wave; ++w) run = run + s_wave[w];
+            s_mom_run = Moments{run.x + (x.x - v.x), run.y + (x.y - v.y), run.z + (x.z - v.z), run.m + (x.m - v.m)};
+        }
+        if (blockIdx.x == 0u) {
+            if (threadIdx.x < kCellRows)
+                row_total[threadIdx.x] = sum8(s_all, threadIdx.x);
+            if (threadIdx.x >= 64u && threadIdx.x < 64u + kBoundSlots) bound_slots[threadIdx.x - 64u] = 0u;
+        }
+    }
     if (wave == 0u) {
         // depth_base[d] = nodes of depth < d, from the rows' totals (row 1 + d = depth d); [kMaxDepth + 1] = the
         // node count.  Every workgroup derives them for itself; the first one publishes them for the kernels
         // that follow (fill, LET export, read-out) and checks the 4N capacity.
-        const uint32_t mine = lane <= (uint32_t)kMaxDepth ? row_total[1u + lane] : 0u;
+        uint32_t mine = 0u;
+        if (lane <= (uint32_t)kMaxDepth)
+            mine = SCAN_INLINE ? sum8(s_all, 1u + lane) : row_total[1u + lane];
         uint32_t x = mine;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o);
@@ -1076,7 +1126,8 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
         }
         const uint32_t base_d = x - mine;  // exclusive
         if (lane <= (uint32_t)kMaxDepth)  // where this tile's nodes of depth d start
-            s_run[lane] = base_d + tile_u32[(size_t)(1u + lane) * stride + blockIdx.x];
+            s_run[lane] = base_d + (SCAN_INLINE ? sum8(s_before, 1u + lane)
+                                                : tile_u32[(size_t)(1u + lane) * stride + blockIdx.x]);
         if (blockIdx.x == 0u) {
             if (lane <= (uint32_t)kMaxDepth) depth_base[lane] = base_d;
             if (lane == (uint32_t)kMaxDepth) {
@@ -1086,9 +1137,18 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
             }
         }
     }
-    uint32_t slot_run = tile_u32[blockIdx.x];  // row 0: opened cells before this tile
-    Moments mom_run = tile_mom[blockIdx.x];
+    uint32_t slot_run = 0u;  // row 0: opened cells before this tile
+    Moments mom_run{0, 0, 0, 0};
+    if (!SCAN_INLINE) {
+        slot_run = tile_u32[blockIdx.x];
+        mom_run = tile_mom[blockIdx.x];
+    }
     __syncthreads();
+    if (SCAN_INLINE) {
+        slot_run = sum8(s_before, 0u);
+        mom_run = s_mom_run;
+        __syncthreads();  // s_wave is reused by the rounds below
+    }
     for (uint32_t sub = 0; sub < rounds; ++sub) {
         const uint32_t k = (blockIdx.x * rounds + sub) * 256u + threadIdx.x;
         const bool valid = k < n;
@@ -2983,7 +3043,7 @@ class TreeSim final : public SimBase {
             }
         }
         bound_from_walk = false;
-        const bool rank_sort = n <= kRankSortMax && sort_mode == 1;
+        const bool rank_sort = n <= rank_sort_max && sort_mode == 1;
         // 3 / 3d: stable radix passes of kSortBits bits -- over all 63 key bits, or (sort_mode 1) only
         // over the top `bits` bits, such that a cell of that level holds 1/64 body on average
         // (2^bits >= 64 N), followed by the fix-up of the runs that tie there.
@@ -3142,11 +3202,17 @@ class TreeSim final : public SimBase {
             hipLaunchKernelGGL((cells_a_kernel<false>), dim3(ct), b256, 0, stream, order, n, posm[s], posm[d], skeys,
                                (uint64_t *)nullptr, cpl, tile_u32, tile_mom, cstride, rounds, status);
         uint32_t *row_total = scalars + 40;  // kCellRows words
-        hipLaunchKernelGGL(cells_scan_kernel, dim3(kCellRows + 4), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
-                           row_total, bound_slots);
-        hipLaunchKernelGGL(cells_c_kernel, dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
-                           depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
-                           rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d], rec);
+        if (ct <= (cell_scan_inline > 1 ? 256u : kCellInlineTiles) && cell_scan_inline) {
+            hipLaunchKernelGGL((cells_c_kernel<true>), dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
+                               depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
+                               rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d], rec, bound_slots);
+        } else {
+            hipLaunchKernelGGL(cells_scan_kernel, dim3(kCellRows + 4), dim3(1024), 0, stream, tile_u32, tile_mom, ct, cstride,
+                               row_total, bound_slots);
+            hipLaunchKernelGGL((cells_c_kernel<false>), dim3(ct), b256, 0, stream, cpl, n, tile_u32, tile_mom, cstride, row_total,
+                               depth_base, n_nodes, status, posm[d], int_slot, leaf_id, int_id, node_first, node_depth, mom_prefix, node_cap,
+                               rounds, order, with_va ? vel[s] : (const float4 *)nullptr, acc[s], vel[d], acc[d], rec, bound_slots);
+        }
         va_gathered = with_va;
         // 6: node contents
         const uint32_t gnodes = (std::min<uint64_t>(node_cap, 3ull * (n / 4u) + 256ull) + 255) / 256;  // internal cells
@@ -3572,9 +3638,19 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
-        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: counting sort (<= 16,384 bodies) / high digits + fix-up;
+        if (std::strcmp(key, "tree_sort_mode") == 0) {  // 1: counting sort (<= 12,288 bodies) / high digits + fix-up;
                                                         // 0: always the full 8-pass radix sort
             sort_mode = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_cell_scan_inline") == 0) {  // 1: cells_c sums the tile table itself up to 64 tiles (default)
+            cell_scan_inline = value;  // (2: up to the 256 tiles the kernel can do)
+            drop_graph();
+            return NB_OK;
+        }
+        if (std::strcmp(key, "tree_rank_sort_max") == 0) {  // the counting sort up to this many bodies (default 12,288)
+            rank_sort_max = (uint32_t)std::max(value, 0);
             drop_graph();
             return NB_OK;
         }
@@ -3703,6 +3779,8 @@ class TreeSim final : public SimBase {
     uint32_t sort_boost = 0, build_seq = 0, run_stat_seq = ~0u, run_stat_seen = ~0u, run_stat_boost = 0;
     bool run_stat_hi = false;
     hipEvent_t *time_walk = nullptr;
+    uint32_t rank_sort_max = kRankSortMax;
+    int cell_scan_inline = 1;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
 };
