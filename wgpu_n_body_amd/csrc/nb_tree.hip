@@ -151,14 +151,17 @@ __global__ __launch_bounds__(256) void bound_kernel(const float4 *__restrict__ p
         atomicMax(bound_bits, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
-// The walk kernels also accumulate the NEXT step's bound from the positions they write (64 slots
-// to spread the atomics; a wave skips the atomic when its value is not above what it reads), so a
-// steady-state step needs neither bound_kernel nor a memset: morton_kernel takes the maximum.
-constexpr uint32_t kBoundSlots = 64;
+// The walk kernels also accumulate the NEXT step's bound from the positions they write, so a steady-state
+// step needs neither bound_kernel nor a memset: morton_kernel takes the maximum of the slots (and of 1.0).
+// A wave whose bodies stay inside the unit cube has nothing to say (the bound is never below 1.0,
+// tree.rs:427-433); the others add their maximum to one of 1,024 slots -- 64 cache lines -- with an atomic
+// nobody waits for.  (Round 2 read the slot first, "skip the atomic when not above": a device-scope load of one
+// of FOUR lines by every wave, in its prologue and waited for -- the lines' channel served ~300 waves per us
+// chip-wide, and a wave of a 32,768-body walk spent 8 us (up to 27) between its launch and its first batch.)
+constexpr uint32_t kBoundSlots = 1024;
 __device__ __forceinline__ void publish_bound(uint32_t *__restrict__ slots, uint32_t key, float m) {
-    uint32_t *slot = slots + (key & (kBoundSlots - 1u));
     const uint32_t bits = __float_as_uint(m);  // non-negative floats order like their bit patterns
-    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    if (bits > 0x3f800000u) atomicMax(slots + (key & (kBoundSlots - 1u)), bits);
 }
 
 // ---- 2. keys ------------------------------------------------------------------------------------
@@ -183,8 +186,19 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
     __shared__ uint32_t s_hist[kSortMaxBins];
     for (uint32_t b = threadIdx.x; b < kSortMaxBins; b += blockDim.x) s_hist[b] = 0;
     __syncthreads();
-    uint32_t bmax = 0;
-    for (uint32_t k = 0; k < n_src; ++k) bmax = max(bmax, bound_src[k]);
+    uint32_t bmax;
+    if (n_src > 1u) {  // the slots of the previous walk: a share per thread, the maximum through LDS
+        __shared__ uint32_t s_bmax[2 * kSortThreads / 64];
+        uint32_t mine = 0;
+        for (uint32_t k = threadIdx.x; k < n_src; k += blockDim.x) mine = max(mine, bound_src[k]);
+        mine = (uint32_t)wave_max_to_lane63((int)mine);  // (bit patterns of non-negative floats: positive as int)
+        if ((threadIdx.x & 63u) == 63u) s_bmax[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        bmax = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64u; ++w) bmax = max(bmax, s_bmax[w]);
+    } else {
+        bmax = bound_src[0];
+    }
     const float bound = fmaxf(1.0f, __uint_as_float(bmax));  // never below 1.0, tree.rs:427-433
     if (blockIdx.x == 0 && threadIdx.x == 0 && bound_src != bound_bits) *bound_bits = __float_as_uint(bound);
     const float root_w = bound * 2.0f;  // root width, tree.rs:465
@@ -1027,7 +1041,8 @@ __global__ __launch_bounds__(1024) void cells_scan_kernel(uint32_t *__restrict__
         return;
     }
     const uint32_t comp = blockIdx.x - kCellRows;  // 0..3: m x, m y, m z, m -- a workgroup per component
-    if (comp == 0u && threadIdx.x < kBoundSlots) bound_slots[threadIdx.x] = 0u;  // this step's walk accumulates the next bound
+    if (comp == 0u)  // this step's walk accumulates the next bound
+        for (uint32_t k = threadIdx.x; k < kBoundSlots; k += 1024u) bound_slots[k] = 0u;
     {   // the moments, by the 1,024 threads in a fixed order: thread t sums the tiles [t S, (t+1) S) in
         // order, the threads' sums are scanned by wave (fixed shuffle tree) and the waves' totals
         // added in wave order -- deterministic whatever the launch timing
@@ -1109,7 +1124,7 @@ __global__ __launch_bounds__(256) void cells_c_kernel(
         if (blockIdx.x == 0u) {
             if (threadIdx.x < kCellRows)
                 row_total[threadIdx.x] = sum8(s_all, threadIdx.x);
-            if (threadIdx.x >= 64u && threadIdx.x < 64u + kBoundSlots) bound_slots[threadIdx.x - 64u] = 0u;
+            for (uint32_t k = threadIdx.x; k < kBoundSlots; k += 256u) bound_slots[k] = 0u;
         }
     }
     if (wave == 0u) {
@@ -1807,6 +1822,14 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     // (readfirstlane: the select between a kernel-argument field and device memory is a load
     // through a flat pointer, which the compiler takes for lane-dependent -- and with it the stack
     // pointer and the whole loop control, which then live in VGPRs under exec masks)
+#if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
+    unsigned long long tl_launch;   // the wave's first instruction
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_launch)::"memory");
+#endif
+#ifdef NB_WALK_START_SLEEP   // experiment: the first waves idle ~N us so that the dispatcher fills the idle SIMDs
+    if (blockIdx.x < 7168u / kCellBlockWaves)
+        for (int i = 0; i < NB_WALK_START_SLEEP; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
     const uint32_t n_roots =
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->count : roots_arg.count));
     using Stack = CellStack<PACKED>;
@@ -1855,9 +1878,6 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
 #define NB_UNIFORM(x) x = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)))
     NB_UNIFORM(blx); NB_UNIFORM(bly); NB_UNIFORM(blz); NB_UNIFORM(bhx); NB_UNIFORM(bhy); NB_UNIFORM(bhz);
 #undef NB_UNIFORM
-    if (bound_slots && lane == 0u)  // the next step's root cube: max |coord| of the new positions
-        publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
-                                                     fmaxf(fabsf(blz), fabsf(bhz))));
     const uint32_t group_mask = ((1u << nvalid) - 1u) << ((uint32_t)G - nvalid);  // body b at bit G - 1 - b
     Ent *stack = s_stack[wave];
     float tx = 0.f, ty = 0.f, tz = 0.f;  // lane b: the finished sums of body b
@@ -1870,7 +1890,12 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     unsigned long long n_visits = 0, n_accepts = 0;
     uint32_t n_cells = 0, n_leaves = 0, n_batches = 0, max_sp = 0, n_idle_pairs = 0, n_evals = 0;
 #ifdef NB_DIAG_PHASES
-    unsigned long long ph[4] = {0, 0, 0, 0};
+    unsigned long long ph[4] = {0, 0, 0, 0};  // cycles per phase
+#endif
+#if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
+    // (three scalars: the probe must not cost the kernel a wave of occupancy)
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();  // the 100 MHz clock
+    uint32_t tl_batches = 0;
 #endif
 
     for (uint32_t set = 0; set < 2u; ++set) {
@@ -1993,6 +2018,9 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             }
             if (COUNT) max_sp = max(max_sp, sp);
             __builtin_amdgcn_wave_barrier();
+#if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
+            tl_batches += 1u;
+#endif
 #ifdef NB_DIAG_PHASES
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"s"(sp));
             const unsigned long long t4 = __builtin_amdgcn_s_memtime();
@@ -2047,10 +2075,23 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
             atomicAdd(&counters[9], (unsigned long long)n_evals);       // batches that ran the pair evaluation
         }
     }
+#if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
+    if (lane == 0u && G == 8) {  // per wave, no atomics: counters + 16 + 8 * group index
+        unsigned long long *out = counters + 16 + 8 * (size_t)((i0 - lo) / (uint32_t)G);
 #ifdef NB_DIAG_PHASES
-    if (lane == 0u)  // per-wave phase cycles, no atomics: counters + 16 + 4 * group index
-        for (int k = 0; k < 4; ++k) counters[16 + 4 * (size_t)((i0 - lo) / (uint32_t)G) + k] = ph[k];
+        for (int k = 0; k < 4; ++k) out[k] = ph[k];
+#else
+        out[0] = 0ull;
 #endif
+        out[4] = tl_batches;   // batches, then the wave's first and last batch on the 100 MHz clock
+        out[5] = tl_start;
+        out[6] = __builtin_amdgcn_s_memrealtime();
+        out[7] = tl_launch;
+    }
+#endif
+    if (bound_slots && lane == 0u)  // the next step's root cube: max |coord| of the new positions (nobody waits)
+        publish_bound(bound_slots, blockIdx.x, fmaxf(fmaxf(fmaxf(fabsf(blx), fabsf(bhx)), fmaxf(fabsf(bly), fabsf(bhy))),
+                                                     fmaxf(fabsf(blz), fabsf(bhz))));
     if (!owner) return;
     if (PART == 1) {
         acc_dst[ib] = float4{tx, ty, tz, 0.f};
@@ -2626,12 +2667,14 @@ class TreeSim final : public SimBase {
         // (the reference's Octant fields -- cogm, bodies, child, the AoS staging: 104 B per node -- are
         // only produced for nb_sim_read_tree and allocated on its first call)
         if (int rc = alloc(&scalars, sizeof(uint32_t) * 128)) return rc;
-        #ifdef NB_DIAG_PHASES
+        #if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
         if (int rc = alloc(&counters, sizeof(unsigned long long) * (16 + nn + 8))) return rc;
 #else
         if (int rc = alloc(&counters, sizeof(unsigned long long) * 16)) return rc;
 #endif
+        if (int rc = alloc(&bound_buf, sizeof(uint32_t) * kBoundSlots)) return rc;
         NB_HIP_TRY(hipMemsetAsync(scalars, 0, sizeof(uint32_t) * 128, stream));
+        NB_HIP_TRY(hipMemsetAsync(bound_buf, 0, sizeof(uint32_t) * kBoundSlots, stream));
         NB_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 16, stream));
         NB_HIP_TRY(hipHostMalloc((void **)&h_status, sizeof(uint32_t) * 12, hipHostMallocDefault));
         return write_particles(host, count);
@@ -3026,7 +3069,7 @@ class TreeSim final : public SimBase {
         const int s = cur, d = cur ^ 1;
         uint32_t *bound_bits = scalars + 0, *n_nodes = scalars + 1, *status = scalars + 4;
         uint32_t *depth_base = scalars + 16;  // kMaxDepth + 2 entries
-        uint32_t *bound_slots = scalars + 64; // kBoundSlots words: the next bound, from the walk
+        uint32_t *bound_slots = bound_buf;    // kBoundSlots words: the next bound, from the walk
         const dim3 b256(256);
         const uint32_t g256 = (n + 255) / 256;
         // 1-2: bound + keys from the step's source positions (old positions, tree.rs:290-295)
@@ -3245,7 +3288,7 @@ class TreeSim final : public SimBase {
         // 8: walk + integrate: sorted source (now in buffer d) -> buffer s.  A walk over the whole state in
         // one launch also leaves max |coord| of the new positions for the next step's root cube.
         const bool whole = part == 0 && !let_world && place.world == 1 && lo == 0 && hi == n;
-        uint32_t *bslots = whole ? scalars + 64 : nullptr;
+        uint32_t *bslots = whole ? bound_buf : nullptr;
         if (time_walk) NB_HIP_TRY(hipEventRecord(time_walk[0], stream));
         if (hi > lo && walk_mode == 0) {
             // bodies per wave: 64 when that still gives >= 4096 waves (4 per SIMD), else halve down to 8
@@ -3701,8 +3744,8 @@ class TreeSim final : public SimBase {
         const std::string nm(name);
         if (nm == "order") { src = order; len = sizeof(uint32_t) * n; }
         else if (nm == "counters") { src = counters; len = sizeof(unsigned long long) * 16; }
-#ifdef NB_DIAG_PHASES
-        else if (nm == "phases") { src = counters + 16; len = sizeof(unsigned long long) * 4 * ((n + 3) / 4); }
+#if defined(NB_DIAG_PHASES) || defined(NB_DIAG_TIMELINE)
+        else if (nm == "phases") { src = counters + 16; len = sizeof(unsigned long long) * 4 * ((n + 3) / 4); }  // (8 words per group of 8)
 #endif
         else if (nm == "status") { src = scalars + 4; len = sizeof(uint32_t) * 4; }
         else if (nm == "depth_base") { src = scalars + 16; len = sizeof(uint32_t) * (kMaxDepth + 2); }
@@ -3753,7 +3796,8 @@ class TreeSim final : public SimBase {
              sort_spare = 6, sort_bits = 0;
     int sort_spare_hi = -1;
     uint32_t *tile_u32 = nullptr;
-    bool bound_from_walk = false;  // scalars[64..128) hold max |coord| of the current state
+    bool bound_from_walk = false;  // bound_buf holds max |coord| of the current state
+    uint32_t *bound_buf = nullptr;  // kBoundSlots words
     bool va_gathered = false;      // the build has already reordered velocities and accelerations
     Moments *tile_mom = nullptr;
     uint32_t cell_tiles = 0;
