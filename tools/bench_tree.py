@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--init", default="uniform")
 ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--scale", type=float, default=1.0, help="positions (and velocities) multiplied by this: a cube wider than [-1, 1]")
 ap.add_argument("--g", type=float, default=None)
 ap.add_argument("--dt", type=float, default=None)
 ap.add_argument("--bpw", type=int, default=None, help="bodies per wave of the walk (default: automatic)")
@@ -38,6 +39,9 @@ if args.g is not None or args.dt is not None:
     sp = nb.SimParams(particle_num=args.bodies, g=args.g if args.g is not None else sp.g,
                       dt=args.dt if args.dt is not None else sp.dt)
 init = getattr(nb.inits, args.init + "_init")(sp, seed=args.seed)
+if args.scale != 1.0:
+    f = nb.as_floats(init)
+    f[:, 0:6] *= args.scale
 sim = nb.TreeSim.from_particles(sp, nb.AddParams.TreeSimParams(args.theta), init)
 if args.mode is not None:
     sim.set_tuning("tree_walk_mode", args.mode)

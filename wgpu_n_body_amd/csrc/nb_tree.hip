@@ -3312,11 +3312,15 @@ class TreeSim final : public SimBase {
 #undef NB_WALK
         } else if (hi > lo) {
             // cells across the lanes (section 8b): a wave walks for a group of G bodies
-            // bodies per wave: 8, or 16 where that measures faster -- wide acceptance (theta >= 0.9), and the
-            // middle sizes at theta >= 0.58 (32,768 .. 262,144 bodies: -5 .. -25 % of the walk; beyond ~400,000 the
-            // two tie, below ~24,000 and at theta 0.5 8 wins: profiles/r03_walk_experiments.txt section 4)
-            const uint32_t walked = hi - lo;
-            const uint32_t gauto = walked >= 24576u && (theta >= 0.9f || (theta >= 0.58f && walked <= 393216u)) ? 16u : 8u;
+            // bodies per wave: 8; 4 on small problems (below 24,576 bodies: twice the waves for the SIMDs a small
+            // walk leaves idle, -5 .. -17 % of the walk at 8,192 and 16,384 bodies); 16 where a wide acceptance test
+            // (theta >= 0.9) meets many bodies (from 393,216: -2 .. -3 %).  Measured after the walk stopped reading
+            // the bound slots in its prologue -- until then a wave's start cost a trip to one hot cache line, and 16
+            // bodies per wave, half the trips, "won" the middle sizes by up to 25 %:
+            // profiles/r03_walk_experiments.txt section 4.
+            // (by the tree's size, not by the range walked: the ranks of a replicated build add the same terms in
+            // the same order as the one-GPU step -- bit for bit its result)
+            const uint32_t gauto = n < 24576u ? 4u : (theta >= 0.9f && n >= 393216u) ? 16u : 8u;
             const uint32_t gsize = walk_group ? walk_group : gauto;
             const uint32_t per_block = kCellBlockWaves * gsize;
             const dim3 gwalk((hi - lo + per_block - 1) / per_block), bwalk(64 * kCellBlockWaves);
