@@ -62,7 +62,10 @@ constexpr int kMaxDepth = kLevels + 1;  // leaves can sit at depth 1..21 (+1 gua
 // -13 us at 131,072 bodies, -5 at 524,288), 8 beyond (half the histogram rows: -14 us at 2^20, -40 at 2^21)
 constexpr uint32_t kSortThreads = 256, kSortItems = 8, kSortItemsSmall = 4, kSortSmallMax = 786432;
 constexpr uint32_t kSortBits = 8, kSortWideBits = 9, kSortMaxBins = 1u << kSortWideBits;  // digit widths (the kernels take 7..9)
-constexpr uint32_t kSortInlineScanBlocks = 32;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
+#ifndef NB_SORT_INLINE_BLOCKS
+#define NB_SORT_INLINE_BLOCKS 32
+#endif
+constexpr uint32_t kSortInlineScanBlocks = NB_SORT_INLINE_BLOCKS;  // up to 32,768 bodies the scatter scans the tile counts itself (-6 %)
 // wave-level stack of sibling groups (16 B each, 3 KiB per wave): a depth-first walk pushes at
 // most 8 groups per level and pops one, so 7 x 21 + 1 = 148 entries is the most it can hold
 constexpr uint32_t kWalkStack = 192;
