@@ -5,7 +5,8 @@ set -e
 cd "$(dirname "$0")/.."
 TAG=${1:-r03}
 O=gpurun_out/${TAG}final
-STATS="$(find gpurun_out/prof_tree_$TAG/trace -name '*kernel_stats.csv' | head -1)"
+# (the newest: gpurun merges every call's process-id-named files into the same directory)
+STATS="$(ls -t $(find gpurun_out/prof_tree_$TAG/trace -name '*kernel_stats.csv') | head -1)"
 for f in $O/bench_n1.json "$STATS" $O/tree_hbm_traffic.txt $O/tree_walk_sq_counters.txt $O/criterion.txt \
          $O/criterion_sizes.json $O/tree_bench.txt $O/tree_bench_cpu_baseline.json $O/headless_cli.txt \
          $O/trace_8192.txt $O/trace_16384.txt $O/trace_131072.txt $O/trace_1048576.txt; do

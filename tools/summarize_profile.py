@@ -26,7 +26,9 @@ KERNEL = "naive_step_kernel"
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     assert hits, pattern
-    return hits[0]
+    # (gpurun merges every call's files into gpurun_out/, and rocprofv3 names them by process id: the NEWEST is this
+    # collection's -- hits[0] once copied a stale summary whose kernel signatures no longer existed)
+    return max(hits, key=os.path.getmtime)
 
 
 stats = one("trace/**/*_kernel_stats.csv")
