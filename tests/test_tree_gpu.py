@@ -515,6 +515,54 @@ def test_tile_scan_inside_cells_c_gives_the_launched_scan_bits(gpu, n, init):
         assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
 
 
+@pytest.mark.parametrize("n,scale", [(4096, 1.0), (50000, 1.0), (3000, 4.0), (3000, 0.3), (20000, 0.5)])
+def test_closed_form_keys_equal_the_descent(gpu, oracle, n, scale):
+    """In a cube whose width is a power of two (every state inside the unit cube: bound 1.0) morton_kernel takes a
+    body's key from ceil(x / h) instead of the 21-level descent of decide_octant / shift_node_center
+    (tree.rs:549-562); `tree_key_descent` 1 forces the descent.  Bodies ON cell boundaries of every level (strict >
+    sends them to the lower cell), on the cube's faces, at denormal distances from a boundary and at +-0 are the
+    cases that could tell the two apart: same order, same tree, same state bit for bit -- and the tree is the
+    oracle's."""
+    nb = gpu
+    rng = np.random.default_rng(n)
+    s = make_state("uniform", n, 77 + n)
+    half = 1.0 if scale <= 1.0 else scale          # max |coord| -> bound (never below 1.0)
+    s[:, 0:3] *= np.float32(scale)
+    k = n // 4                                      # a quarter of the bodies onto cell boundaries of random levels
+    lev = rng.integers(1, 22, size=(k, 3))
+    cells = rng.integers(0, 2 ** 21, size=(k, 3)) >> (21 - lev)
+    edge = (cells.astype(np.float64) * (2.0 * half) / (2.0 ** lev) - half).astype(np.float32)
+    s[:k, 0:3] = edge
+    tiny = np.float32(1e-42)
+    s[k:k + 64, 0] = np.nextafter(s[:64, 0], np.float32(np.inf))     # just above a boundary
+    s[k + 64:k + 128, 1] = np.nextafter(s[:64, 1], np.float32(-np.inf))
+    s[k + 128, 0:3] = (half, half, half)
+    s[k + 129, 0:3] = (-half, -half, -half)
+    s[k + 130, 0:3] = (0.0, -0.0, tiny)
+    s[k + 131, 0:3] = (-tiny, tiny, 0.0)
+    s[:, 0:3] = np.clip(s[:, 0:3], np.float32(-half), np.float32(half))   # (a step beyond a face would widen the cube)
+    # no two bodies in one finest cell (the octree could not separate them): later duplicates are drawn again
+    h = 2.0 * half / 2.0 ** 21
+    for _ in range(20):
+        cell = np.clip(np.ceil((s[:, 0:3].astype(np.float64) + half) / h) - 1, 0, 2 ** 21 - 1).astype(np.int64)
+        code = (cell[:, 0] << 42) | (cell[:, 1] << 21) | cell[:, 2]
+        _, first = np.unique(code, return_index=True)
+        dup = np.setdiff1d(np.arange(n), first)
+        if not len(dup):
+            break
+        s[dup, 0:3] = rng.uniform(-half, half, size=(len(dup), 3)).astype(np.float32) * np.float32(0.999)
+    a = run_tree(nb, s, 0.75, steps=2, count=False)
+    b = run_tree(nb, s, 0.75, steps=2, count=False, tuning={"tree_key_descent": 1})
+    assert not a["status"].any() and not b["status"].any()
+    assert np.array_equal(a["order"], b["order"])
+    assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
+    assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
+    ref = oracle.tree_step_f32(s, G, E, DT, 0.75, flags=oracle.INTENDED)
+    one = run_tree(nb, s, 0.75, steps=1)
+    check_tree(one["tree"], one["root_width"], one["order"], ref["tree"], ref["root_width"], ref["order"],
+               extent=float(np.abs(s[:, 0:3]).max()))
+
+
 def test_random_cases_against_oracle(gpu, oracle):
     """tools/tree_fuzz.py, 80 cases of a fixed seed: size (1 .. 30,000), distribution, theta (0.3 .. 1.3), scale of
     the cube (0.01 .. 300), walk shape, sort path and tile-scan form drawn at random; tree and order bit-exact,

@@ -1,4 +1,3 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 &&
-timeout -k 10 400 python tools/small_n.py --sizes 1024,8192,16384,32768,65536,131072 --thetas 0.75 - 2>&1 | tail -20
+timeout -k 10 600 python -m pytest tests/test_tree_gpu.py -x -q -m gpu -k "closed_form" 2>&1 | tail -30

@@ -167,6 +167,23 @@ __device__ __forceinline__ void publish_bound(uint32_t *__restrict__ slots, uint
     if (bits > 0x3f800000u) atomicMax(slots + (key & (kBoundSlots - 1u)), bits);
 }
 
+// (see morton_kernel) the cell of a coordinate at the finest level, and its 21 bits spread to every third bit
+__device__ __forceinline__ uint32_t cell_21(float x, float inv_h) {
+    const int t = (int)__builtin_ceilf(x * inv_h) + (1 << 20) - 1;
+    return (uint32_t)min(max(t, 0), (1 << 21) - 1);
+}
+__device__ __forceinline__ uint64_t spread_21(uint32_t v) {
+    // the low 11 and the high 10 bits separately, in 32-bit arithmetic: bit i -> bit 3 i
+    auto spread = [](uint32_t x) {  // x < 2^11
+        x = (x | (x << 16)) & 0x070000ffu;
+        x = (x | (x << 8)) & 0x0700f00fu;
+        x = (x | (x << 4)) & 0x430c30c3u;
+        x = (x | (x << 2)) & 0x49249249u;
+        return x;
+    };
+    return (uint64_t)spread(v & 0x7ffu) | ((uint64_t)spread(v >> 11) << 33);
+}
+
 // ---- 2. keys ------------------------------------------------------------------------------------
 // One workgroup per sort tile: the keys, and the tile's histogram of the first digit (saves the
 // first pass its histogram launch).
@@ -180,7 +197,8 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
                                                               uint32_t *__restrict__ idx,
                                                               uint32_t *__restrict__ hist, uint32_t nblocks,
                                                               uint32_t items, uint32_t hist_shift,
-                                                              uint32_t hist_bins, uint32_t *__restrict__ key_hi) {
+                                                              uint32_t hist_bins, uint32_t *__restrict__ key_hi,
+                                                              uint32_t key_descent_only) {
     // key_hi (the radix passes sort 32-bit high words paired with indices, section 3e): the high word of
     // every key beside the key, and no identity index array -- the first pass makes it up.
     // (blockDim.x * items bodies = a sort tile: a workgroup leaves the tile's histogram of the digit the
@@ -209,6 +227,8 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
     // of two times root_w, i.e. root_w's bit pattern with its exponent lowered -- wave-uniform integers the scalar
     // unit computes, where `w / 4.0f; w = w / 2.0f` cost two vector multiplies per level and body.
     const uint32_t root_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(root_w));
+    const bool pow2_root = (root_bits & 0x007fffffu) == 0u && !key_descent_only;
+    const float inv_h = __uint_as_float((275u - (root_bits >> 23)) << 23);  // 2^21 / root_w for a power of two
     // (the loads of a tile's bodies first, all in flight together: one body after the other the
     // kernel waited out eight memory latencies per thread)
     float4 pv[kSortItems];
@@ -222,17 +242,27 @@ __global__ __launch_bounds__(2 * kSortThreads) void morton_kernel(const float4 *
         const uint32_t i = (blockIdx.x * items + c) * blockDim.x + threadIdx.x;
         if (c >= items || i >= n) break;
         const float4 p = pv[c];
-        float cx = 0.f, cy = 0.f, cz = 0.f;
         uint64_t key = 0;
+        if (pow2_root) {
+            // root_w a power of two (every state inside the unit cube: bound = 1.0): the centres of the descent
+            // below are multiples of root_w / 2^22 below root_w / 2 -- at most 21 significant bits, exact in fp32 --
+            // so its 21 strict comparisons spell the binary digits of ceil((x + root_w / 2) / h) - 1, h = root_w /
+            // 2^21 the finest cell (a body ON a cell boundary belongs below it; x = -root_w / 2 gives all zeros).
+            // x / h is an exact scaling, its ceiling an exact integer of at most 21 bits: three instructions per
+            // axis and a bit interleave instead of 21 dependent levels of compare, select, add.
+            key = spread_21(cell_21(p.x, inv_h)) | (spread_21(cell_21(p.y, inv_h)) << 1) | (spread_21(cell_21(p.z, inv_h)) << 2);
+        } else {
+            float cx = 0.f, cy = 0.f, cz = 0.f;
 #pragma unroll
-        for (int l = 0; l < kLevels; ++l) {
+            for (int l = 0; l < kLevels; ++l) {
 #pragma clang fp contract(off)
-            const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
-            key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
-            const float q = __uint_as_float(root_bits - ((uint32_t)(l + 2) << 23));  // (root_w / 2^l) / 4, exactly
-            cx = cx + (bx ? q : -q);  // shift_node_center
-            cy = cy + (by ? q : -q);
-            cz = cz + (bz ? q : -q);
+                const uint32_t bx = p.x > cx, by = p.y > cy, bz = p.z > cz;  // decide_octant, strict >
+                key = (key << 3) | (uint64_t)(bx | (by << 1) | (bz << 2));
+                const float q = __uint_as_float(root_bits - ((uint32_t)(l + 2) << 23));  // (root_w / 2^l) / 4, exactly
+                cx = cx + (bx ? q : -q);  // shift_node_center
+                cy = cy + (by ? q : -q);
+                cz = cz + (bz ? q : -q);
+            }
         }
         keys[i] = key;
         if (key_hi) key_hi[i] = (uint32_t)(key >> 32);
@@ -3132,13 +3162,13 @@ class TreeSim final : public SimBase {
         if (rank_sort)
             hipLaunchKernelGGL(morton_kernel, dim3((n + kSortThreads - 1) / kSortThreads), dim3(kSortThreads), 0, stream,
                                posm[s], n, bound_src, n_src, bound_bits, keys[0], idx[0], (uint32_t *)nullptr, 0u, 1u,
-                               0u, 1u, (uint32_t *)nullptr);
+                               0u, 1u, (uint32_t *)nullptr, key_descent);
         else  // (with the tile histograms of the first pass's digit)
             // (512 threads x half the sort's items per thread: the same tile, twice the waves per SIMD for the
             // 21 dependent levels of the key descent)
             hipLaunchKernelGGL(morton_kernel, dim3(sort_blocks), dim3(2 * kSortThreads), 0, stream, posm[s], n, bound_src,
                                n_src, bound_bits, keys[0], idx[0], hist, sort_blocks, sort_items / 2u,
-                               hi_mode ? 32u + hs0 : shift0, bins, hi_mode ? khi[0] : (uint32_t *)nullptr);
+                               hi_mode ? 32u + hs0 : shift0, bins, hi_mode ? khi[0] : (uint32_t *)nullptr, key_descent);
         int kb = 0;
         if (rank_sort) {
             // 3c: the sorted position of every body counted in one launch
@@ -3694,6 +3724,11 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_key_descent") == 0) {  // 1: the keys by the 21-level descent even in a power-of-two cube
+            key_descent = value != 0 ? 1u : 0u;
+            drop_graph();
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_cell_scan_inline") == 0) {  // 1: cells_c sums the tile table itself up to 64 tiles (default)
             cell_scan_inline = value;  // (2: up to the 256 tiles the kernel can do)
             drop_graph();
@@ -3831,6 +3866,7 @@ class TreeSim final : public SimBase {
     bool run_stat_hi = false;
     hipEvent_t *time_walk = nullptr;
     uint32_t rank_sort_max = kRankSortMax;
+    uint32_t key_descent = 0;
     int cell_scan_inline = 1;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
