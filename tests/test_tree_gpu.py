@@ -563,6 +563,45 @@ def test_closed_form_keys_equal_the_descent(gpu, oracle, n, scale):
                extent=float(np.abs(s[:, 0:3]).max()))
 
 
+@pytest.mark.parametrize("n,init,steps", [(1, "uniform", 3), (7, "uniform", 2), (1000, "spherical", 5), (20000, "disc", 4),
+                                          (300000, "uniform", 3)])
+def test_walk_that_gathers_velocities_gives_the_sorted_copys_bits(gpu, n, init, steps):
+    """From 524,288 bodies the walk fetches a body's velocity and acceleration through the order itself instead of
+    having cells_c_kernel sort them first, writes the new position over the sorted old one and the state lands in the
+    other buffer set (`cur` flips every step); `tree_walk_gathers` 0 / 2 force either form at any size.  Same values,
+    same operations: state, order and the tree read back after the last step (its leaves from the walk records:
+    the sorted source positions are gone by then) bit for bit, after an odd and an even number of steps, and
+    through write_particles / a phase-split step in between."""
+    nb = gpu
+    sp = nb.SimParams(particle_num=n)
+    state = nb.as_floats(getattr(nb.inits, init + "_init")(sp, seed=5 + n % 83))
+    g, dt = (1e-5, 0.0016) if init == "disc" else (G, DT)
+    for k in (steps, steps + 1):
+        a = run_tree(nb, state, 0.75, steps=k, g=g, dt=dt, count=False, tuning={"tree_walk_gathers": 0})
+        b = run_tree(nb, state, 0.75, steps=k, g=g, dt=dt, count=False, tuning={"tree_walk_gathers": 2})
+        assert not a["status"].any() and not b["status"].any()
+        assert np.array_equal(a["order"], b["order"])
+        assert np.array_equal(bits(a["dst"]), bits(b["dst"]))
+        assert a["tree"].tobytes() == b["tree"].tobytes() and a["root_width"] == b["root_width"]
+    # mixed: whole steps (gathering), a step in two phases (never gathers), a new state, more whole steps
+    sp2 = nb.SimParams(particle_num=n, g=g, dt=dt)
+    sims = []
+    for mode in (0, 2):
+        sim = nb.TreeSim.from_particles(sp2, nb.AddParams.TreeSimParams(0.75), state)
+        sim.set_tuning("tree_walk_gathers", mode)
+        sim.encode(); sim.encode()
+        sim.encode_phase(0); sim.encode_phase(1)
+        sim.encode()
+        mid = nb.as_floats(sim.dest_particle_slice()).copy()
+        sim.write_particles(nb.as_particles(state))
+        sim.encode(); sim.encode(); sim.encode()
+        sim.wait()
+        sims.append((mid, nb.as_floats(sim.dest_particle_slice()).copy()))
+        sim.destroy()
+    assert np.array_equal(bits(sims[0][0]), bits(sims[1][0]))
+    assert np.array_equal(bits(sims[0][1]), bits(sims[1][1]))
+
+
 def test_random_cases_against_oracle(gpu, oracle):
     """tools/tree_fuzz.py, 80 cases of a fixed seed: size (1 .. 30,000), distribution, theta (0.3 .. 1.3), scale of
     the cube (0.01 .. 300), walk shape, sort path and tile-scan form drawn at random; tree and order bit-exact,

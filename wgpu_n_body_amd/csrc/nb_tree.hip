@@ -1342,7 +1342,9 @@ __global__ void fill_kernel(const uint64_t *__restrict__ keys, uint32_t n, uint3
         const uint32_t dd = AOS ? node_depth[id] : si.y >> kSlotDepthShift;
         uint32_t ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (dd & 0x80) {  // leaf: cog = position, mass, bodies = 1, children[0] = source index
-            const float4 p = posm[k];
+            // (AOS, the read-out after a step: from the record cells_c_kernel wrote -- a walk that gathers velocities
+            // has put the NEW positions where the sorted source stood)
+            const float4 p = AOS ? rec[id].cogm : posm[k];
             if (AOS) {
                 cogm[id] = p;
                 bodies[id] = 1;
@@ -1747,6 +1749,7 @@ constexpr uint32_t kCellStack = NB_CELL_STACK;  // entries per wave, two-word fo
 #endif
 constexpr uint32_t kCellStackPacked = NB_CELL_STACK_PACKED;  // ... one-word form
 constexpr uint32_t kCellReserve = 160;
+constexpr uint32_t kWalkGatherFrom = 524288;  // bodies from which the walk gathers velocities itself (8c)
 
 // sum over the 64 lanes, in a fixed order; the total lands in lane 63
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
@@ -1844,12 +1847,16 @@ __device__ __forceinline__ uint32_t cells_batch(const float4 q, const float mac2
 template <int G, bool COUNT, int PART, bool PACKED>
 // (G <= 8: at most 96 VGPRs, so that five waves fit a SIMD -- the compiler lands on 90..100 by itself)
 __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAVES : NB_WALK_WAVES)) void walk_cells_kernel(
-    const float4 *__restrict__ posm_src, const float4 *__restrict__ vel_src,
+    const float4 *posm_src, const float4 *__restrict__ vel_src,
     const float4 *__restrict__ acc_src, const NodeRec *__restrict__ rec, WalkRoots roots_arg, uint32_t split,
-    float4 *__restrict__ posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
+    float4 *posm_dst, float4 *__restrict__ vel_dst, float4 *__restrict__ acc_dst,
     uint32_t lo, uint32_t hi, float g, float e, float dt,
     uint32_t *__restrict__ status, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev) {
+    uint32_t *__restrict__ bound_slots, const WalkRoots *__restrict__ roots_dev,
+    const uint32_t *__restrict__ va_order) {
+    // va_order (section 8c): velocities and accelerations are still in the step's SOURCE order -- body k's are at
+    // va_order[k] -- and the new position goes where the sorted old one was read (posm_dst == posm_src: only the
+    // group itself ever reads its bodies' entries, the tree's records carry their own copies)
     // (device-made roots: fixed-stride LET imports.  Element-wise, never a copy of the struct: a
     // by-value copy of a kernel argument selected at run time lands in scratch memory)
     // (readfirstlane: the select between a kernel-argument field and device memory is a load
@@ -1885,7 +1892,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     const uint32_t ic = owner ? ib : i0;
     float xi, yi, zi;
     {   // kick + drift (tree.wgsl:105-106); redone after the walk instead of kept in registers
-        const float4 p = posm_src[ic], v = vel_src[ic], a = acc_src[ic];
+        const uint32_t jc = va_order ? va_order[ic] : ic;
+        const float4 p = posm_src[ic], v = vel_src[jc], a = acc_src[jc];
         xi = drift(p.x, kick(v.x, a.x, dt), dt);
         yi = drift(p.y, kick(v.y, a.y, dt), dt);
         zi = drift(p.z, kick(v.z, a.z, dt), dt);
@@ -2133,7 +2141,8 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     const float gdt = g * dt;
     const float fx = tx * gdt, fy = ty * gdt, fz = tz * gdt;
     // the same loads and the same operations as before the walk: bit for bit the same half kick
-    const float4 p = posm_src[ib], v = vel_src[ib], a = acc_src[ib];
+    const uint32_t jb = va_order ? va_order[ib] : ib;
+    const float4 p = posm_src[ib], v = vel_src[jb], a = acc_src[jb];
     const float vhx = kick(v.x, a.x, dt), vhy = kick(v.y, a.y, dt), vhz = kick(v.z, a.z, dt);
     posm_dst[ib] = float4{drift(p.x, vhx, dt), drift(p.y, vhy, dt), drift(p.z, vhz, dt), p.w};
     vel_dst[ib] = float4{kick(vhx, fx, dt), kick(vhy, fy, dt), kick(vhz, fz, dt), 0.f};
@@ -3089,10 +3098,17 @@ class TreeSim final : public SimBase {
             set_error("this TreeSim runs the LET protocol: use nb_sim_encode_phase(NB_PHASE_LET_*)");
             return NB_ERR_INVALID;
         }
+        // 8c: from kWalkGatherFrom bodies the walk fetches a body's velocity and acceleration through the order
+        // itself instead of having cells_c_kernel copy all of them into sorted arrays first (64 B read + 64 B
+        // written per body by a kernel that runs at the HBM limit); the new state then lands in the OTHER buffer set
+        // (positions in place over the sorted source) and `cur` flips.  Whole one-GPU steps only; not under a captured
+        // graph (its arguments would alternate).
+        const bool gather = !build_done && place.world == 1 && !use_graph && walk_mode != 0 && walk_gathers != 0 &&
+                            (walk_gathers > 1 || n >= kWalkGatherFrom);
         if (!build_done)
-            if (int rc = enqueue_build(false, place.world == 1)) return rc;
+            if (int rc = enqueue_build(false, place.world == 1 && !gather)) return rc;
         build_done = false;
-        return enqueue_walk(own_root());
+        return enqueue_walk(own_root(), 0, 1, nullptr, gather);
     }
 
     // external_bound: the root cube is already in scalars[0] (LET: the max over all ranks)
@@ -3310,11 +3326,11 @@ class TreeSim final : public SimBase {
 
     // part: 0 whole step, 1 own-tree sums only, 2 continue from those sums and integrate
     int enqueue_walk(const WalkRoots &roots, int part = 0, uint32_t split = 1,
-                     const WalkRoots *roots_dev = nullptr) {
+                     const WalkRoots *roots_dev = nullptr, bool gather = false) {
         const int s = cur, d = cur ^ 1;
         uint32_t *status = scalars + 4;
         const dim3 b256(256);
-        if (part != 2 && !va_gathered)
+        if (part != 2 && !va_gathered && !gather)
             hipLaunchKernelGGL(gather_va_kernel, dim3((n + 255) / 256), b256, 0, stream, order, n, vel[s], acc[s],
                                vel[d], acc[d]);
         va_gathered = false;
@@ -3360,10 +3376,16 @@ class TreeSim final : public SimBase {
             // one-word stack entries when the group has 8 mask bits and every id is below 2^24
             const uint64_t id_limit = (uint64_t)node_cap + (let_world ? (uint64_t)let_world * let_cap : 0ull);
             const bool packed = walk_packed != 0 && gsize <= 8u && id_limit <= (1ull << kPackedIdBits);
+            // (gather: sorted positions in buffer d, velocities / accelerations in source order in buffer s; the new
+            // state -> buffer d)
+            const float4 *w_vel = gather ? vel[s] : vel[d], *w_acc = gather ? acc[s] : acc[d];
+            float4 *w_posm_dst = gather ? posm[d] : posm[s], *w_vel_dst = gather ? vel[d] : vel[s],
+                   *w_acc_dst = gather ? acc[d] : acc[s];
+            const uint32_t *w_order = gather ? order : nullptr;
 #define NB_WALK(G, COUNT, PART, PACKED)                                                                           \
-    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART, PACKED>), gwalk, bwalk, 0, stream, posm[d], vel[d],      \
-                       acc[d], rec, roots, split, posm[s], vel[s], acc[s], lo, hi, params.g, params.e, params.dt, \
-                       status, counters, bslots, roots_dev)
+    hipLaunchKernelGGL((walk_cells_kernel<G, COUNT, PART, PACKED>), gwalk, bwalk, 0, stream, posm[d], w_vel,       \
+                       w_acc, rec, roots, split, w_posm_dst, w_vel_dst, w_acc_dst, lo, hi, params.g, params.e,    \
+                       params.dt, status, counters, bslots, roots_dev, w_order)
 #define NB_WALK_P(G, COUNT, PACKED)                                                           \
     do {                                                                                      \
         if (part == 0) NB_WALK(G, COUNT, 0, PACKED);                                          \
@@ -3385,6 +3407,8 @@ class TreeSim final : public SimBase {
         NB_HIP_TRY(hipGetLastError());
         bound_from_walk = whole && hi > lo;
         // the post-step state is in buffer s (= cur); buffer d holds the sorted source
+        // (gather: the post-step state is in buffer d, which becomes cur; s keeps the unsorted source)
+        if (gather && hi > lo && walk_mode != 0) cur = d;
         return NB_OK;
     }
 
@@ -3724,6 +3748,11 @@ class TreeSim final : public SimBase {
             drop_graph();
             return NB_OK;
         }
+        if (std::strcmp(key, "tree_walk_gathers") == 0) {  // 1: the walk gathers velocities from kWalkGatherFrom bodies (default),
+                                                          // 0: cells_c sorts them first at every size, 2: gathers at every size
+            walk_gathers = value;
+            return NB_OK;
+        }
         if (std::strcmp(key, "tree_key_descent") == 0) {  // 1: the keys by the 21-level descent even in a power-of-two cube
             key_descent = value != 0 ? 1u : 0u;
             drop_graph();
@@ -3867,6 +3896,7 @@ class TreeSim final : public SimBase {
     hipEvent_t *time_walk = nullptr;
     uint32_t rank_sort_max = kRankSortMax;
     uint32_t key_descent = 0;
+    int walk_gathers = 1;
     int cell_scan_inline = 1;
     std::vector<void *> allocs;
     std::vector<hipEvent_t> events;
