@@ -98,6 +98,8 @@ class LetGroup:
     def _copy(self, dst, src, nbytes):
         if nbytes:
             assert self.hip.hipMemcpy(dst, src, nbytes, 3) == 0  # device to device
+            # (it may return before the copy has run, and the simulators' streams do not wait for the null stream)
+            assert self.hip.hipDeviceSynchronize() == 0
 
     def _all_gather(self, k):
         regs = []

@@ -295,6 +295,10 @@ def test_sharded_ranks_reproduce_the_single_simulator(gpu, n, world, jsplit):
             for dst_rank, (dp_ptr, _o, _l, _t) in enumerate(regions):
                 if dst_rank != src_rank:
                     assert hip.hipMemcpy(dp_ptr + off, sp_ptr + off, ln, 3) == 0  # DtoD
+        # (a device-to-device hipMemcpy may return before the copy has run, and the simulators' own streams do
+        # not wait for the null stream: without this the next step could read a slice that is still on its way --
+        # seen once in ~10 runs of the whole suite as a mismatch of the last step's accelerations)
+        assert hip.hipDeviceSynchronize() == 0
     want = nb.as_floats(single.dest_particle_slice())
     per = nb.shard_bodies_per_rank(n, world)
     for r, s in enumerate(sims):
