@@ -295,7 +295,10 @@ int nb_sim_encode_n_timed(nb_sim *sim, int n, float *ms_total, float *ms_kernel)
 /* Tuning knobs with no reference counterpart.  key "naive_variant": index into the
  * all-pairs kernel variant table (tiling / packing choices of nb_naive.hip; every variant
  * computes the same step).  Also settable through the NB_NAIVE_VARIANT environment
- * variable at create time. */
+ * variable at create time.  A TreeSim's keys ("tree_*": bodies per wave of the walk, sort
+ * passes and fix-up, who gathers the velocities, where the tile scan runs, ...) are listed
+ * with their defaults in TreeSim::set_tuning (nb_tree.hip): speed only -- every setting
+ * computes the same step, bit for bit where the tests say so. */
 int nb_sim_set_tuning(nb_sim *sim, const char *key, int value);
 int nb_naive_variant_count(void);
 const char *nb_naive_variant_name(int variant);
