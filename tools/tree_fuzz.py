@@ -35,6 +35,10 @@ def fuzz(budget=60.0, seed=1, max_cases=None, log=print):
             shape["tree_cell_scan_inline"] = int(rng.integers(3))
         if rng.integers(4) == 0:
             shape["tree_rank_sort_max"] = int(rng.choice([0, 1 << 20]))
+        if rng.integers(3) == 0:
+            shape["tree_walk_gathers"] = int(rng.choice([0, 2]))
+        if rng.integers(4) == 0:
+            shape["tree_key_descent"] = 1
         tag = f"{kind} n={n} theta={theta} scale={scale} {shape}"
         cases += 1
         try:
@@ -53,8 +57,16 @@ def fuzz(budget=60.0, seed=1, max_cases=None, log=print):
             err = rel_err(r["dst"][:, 6:9], ref["dst"][:, 6:9])
             assert np.median(err) < 1e-5, np.median(err)
             assert np.percentile(err, 99) < 1e-4, np.percentile(err, 99)
-            assert err.max() < 5e-2 * max(1.0, (theta / 0.75) ** 2) * 2.0, err.max()
             assert (err > 1e-3).sum() <= max(2, int(2e-4 * n)), (err > 1e-3).sum()
+            # the worst body: one flipped acceptance test costs it that cell's approximation error -- a few per cent
+            # of the CELL's pull, which can be a large part of the body's NET acceleration where the pulls cancel
+            # (the middle of a uniform cube).  Measured against the typical acceleration as well:
+            worst = int(np.argmax(err))
+            a_ref = np.linalg.norm(ref["dst"][:, 6:9].astype(np.float64), axis=1)
+            d_abs = np.linalg.norm(r["dst"][worst, 6:9].astype(np.float64) - ref["dst"][worst, 6:9].astype(np.float64))
+            cap = 5e-2 * max(1.0, (theta / 0.75) ** 2) * 2.0
+            assert err[worst] < cap or d_abs < cap * np.median(a_ref), (
+                worst, err[worst], d_abs / np.median(a_ref), a_ref[worst] / np.median(a_ref))
             # (an acceptance test within an ulp of theta may flip -- size^2 / theta^2 < r^2 here, the oracle's
             # literal form there -- and takes the cell's subtree in or out of the walk: reported, and bounded)
             dv = int(r["counters"][0]) - ref["stats"]["visits"]

@@ -1866,10 +1866,6 @@ __global__ __launch_bounds__(64 * NB_WALK_BLOCK_WAVES, (G <= 8 ? NB_WALK_MIN_WAV
     unsigned long long tl_launch;   // the wave's first instruction
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_launch)::"memory");
 #endif
-#ifdef NB_WALK_START_SLEEP   // experiment: the first waves idle ~N us so that the dispatcher fills the idle SIMDs
-    if (blockIdx.x < 7168u / kCellBlockWaves)
-        for (int i = 0; i < NB_WALK_START_SLEEP; ++i) __builtin_amdgcn_s_sleep(32);
-#endif
     const uint32_t n_roots =
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(roots_dev ? roots_dev->count : roots_arg.count));
     using Stack = CellStack<PACKED>;
