@@ -33,6 +33,13 @@ for n in 8192 16384 131072 1048576; do
   bash tools/trace_tree.sh ${TAG}_$n --bodies $n --theta $([ $n = 1048576 ] && echo 0.5 || echo 0.75) > $O/trace_$n.txt 2>&1 || { tail $O/trace_$n.txt; exit 1; }
   need $O/trace_$n.txt
 done
+# when the waves of the walk ran (a -DNB_DIAG_TIMELINE build of the same sources: tools/build_variant.sh timeline -DNB_DIAG_TIMELINE)
+if [ -s wgpu_n_body_amd/_variants/timeline.so ]; then
+  for n in 8192 32768 131072 1048576; do
+    NB_LIB=wgpu_n_body_amd/_variants/timeline.so python tools/walk_timeline.py $n 0.75 >> $O/walk_timeline.txt 2>&1 || { tail $O/walk_timeline.txt; exit 1; }
+  done
+  NB_LIB=wgpu_n_body_amd/_variants/timeline.so python tools/walk_timeline.py 1048576 0.5 >> $O/walk_timeline.txt 2>&1 || true
+fi
 ./wgpu_n_body_amd/headless > $O/headless_cli.txt 2>&1
 ./wgpu_n_body_amd/headless --sim naive --n 65536 --steps 5 --devices 0,0,0,0,0,0,0,0 >> $O/headless_cli.txt 2>&1
 need $O/headless_cli.txt

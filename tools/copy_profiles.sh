@@ -28,6 +28,11 @@ for n in 8192 16384 131072 1048576; do
   cat $O/trace_$n.txt >> profiles/${TAG}_step_timelines.txt
 done
 cp $O/headless_cli.txt profiles/${TAG}_headless_cli.txt
+if [ -s $O/walk_timeline.txt ]; then
+  { echo "# tools/walk_timeline.py on a -DNB_DIAG_TIMELINE build (8 bodies per wave): every wave of the walk leaves the 100 MHz clock"
+    echo "# at its first instruction (launch), at its first batch (start) and after its last (end), and its batch count."
+    grep -v "amdgpu.ids" $O/walk_timeline.txt; } > profiles/${TAG}_walk_timeline.txt
+fi
 if [ -s $O/tree_let_per_rank.json ]; then grep '^{' $O/tree_let_per_rank.json | tail -1 > profiles/${TAG}_tree_let_per_rank.json; fi
 if [ -s $O/let_export.txt ]; then
   { echo "# tools/let_export_latency.py: NB_PHASE_LET_BUILD (octree of the rank's bodies + LET export for 7 peers) of ONE rank"
